@@ -1,0 +1,160 @@
+/* smd_hip.h -- C-ABI of libsmd_hip.so, the MI355X (gfx950) DDPM train + sample engine.
+ *
+ * The reference (magenta/symbolic-music-diffusion) has no FFI: its seam for this path is a set
+ * of Python callables.  Each entry point below names the reference callable
+ * (file:line under the reference repo root) whose arithmetic it replaces; INTEGRATION.md shows the
+ * ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All `void*`/`float*` data pointers are
+ *     DEVICE pointers borrowed from the caller (never freed, never retained past the handle's
+ *     bindings).  `stream` is a hipStream_t passed as void*.  Calls only enqueue work.
+ *   - return value: 0 ok; < 0 argument / state error; > 0 a hipError_t.  smd_last_error() returns
+ *     a thread-local message for the last non-zero return.
+ *   - bf16 buffers are uint16 storage (`smd_bf16`).  GEMM operands are row-major with the
+ *     contraction dimension padded to a multiple of 64 (zero filled).
+ *   - no global mutable state; entry points are re-entrant and stream-ordered.
+ */
+#ifndef SMD_HIP_H_
+#define SMD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMD_ABI_VERSION 1
+
+typedef uint16_t smd_bf16;
+typedef struct smd_engine smd_engine;
+
+const char* smd_last_error(void);
+int smd_abi_version(void);
+
+/* ---- model description: the kwargs of train_ncsn.py:321-326 + data shape ---------------------- */
+typedef struct smd_model_desc {
+  int32_t arch;            /* 0 TransformerDDPM (models/ncsn.py:138-179), 1 DenseDDPM (:122-135) */
+  int32_t data_channels;   /* C */
+  int32_t seq_len;         /* S (32; 1 for DenseDDPM) */
+  int32_t num_layers;      /* --num_layers       train_ncsn.py:69 */
+  int32_t num_heads;       /* --num_heads        train_ncsn.py:70 */
+  int32_t num_mlp_layers;  /* --num_mlp_layers   train_ncsn.py:71 */
+  int32_t mlp_dims;        /* --mlp_dims         train_ncsn.py:72 */
+  int32_t embed_channels;  /* 128, models/ncsn.py:151 */
+  int32_t film_channels;   /* 128, models/ncsn.py:174 */
+  int32_t num_timesteps;   /* --num_sigmas       train_ncsn.py:81 */
+} smd_model_desc;
+
+/* ---- engine handle ---------------------------------------------------------------------------- */
+/* replaces train_ncsn.create_model (train_ncsn.py:193-203): builds the parameter layout only */
+int smd_engine_create(const smd_model_desc* desc, smd_engine** out);
+void smd_engine_destroy(smd_engine* e);
+
+/* parameter pytree as a flat fp32 buffer: tensor i = (name, element offset, rows, cols[0 = 1-D]) */
+int smd_engine_num_tensors(const smd_engine* e);
+int smd_engine_tensor_info(const smd_engine* e, int i, const char** name, int64_t* offset, int32_t* rows,
+                           int32_t* cols);
+int64_t smd_engine_param_count(const smd_engine* e);
+int64_t smd_engine_head_param_offset(const smd_engine* e);  /* first parameter of the output stage */
+int64_t smd_engine_wpack_elems(const smd_engine* e);        /* bf16 elements of the GEMM operand pack */
+int64_t smd_engine_workspace_bytes(const smd_engine* e, int batch, int training);
+int64_t smd_engine_film_table_floats(const smd_engine* e);
+int smd_engine_padded_channels(const smd_engine* e);
+int smd_engine_set_option(smd_engine* e, const char* key, int value);  /* "tr_path": 1 | 0 */
+
+int smd_engine_bind_params(smd_engine* e, float* params, smd_bf16* wpack);
+int smd_engine_bind_train(smd_engine* e, float* grads, float* adam_m, float* adam_v, float* ema /*nullable*/,
+                          uint32_t* step_counter, float* metrics /*[4]: |g|, |g| clipped, lr, step*/);
+int smd_engine_bind_workspace(smd_engine* e, void* workspace, int64_t bytes, int batch, int training,
+                              void* stream);
+/* coef [T][8] = (sqrt(1/ap), sqrt(1-ap)/sqrt(ap), mu1, mu2, sigma, ap, sqrt(ap), sqrt(1-ap)) per t
+ * (utils/ebm_utils.py:332-358); sqrt_ap [T]; alphas_prod_ext [T+1] = [1, cumprod(1-beta)]
+ * (utils/losses.py:277-281); film_tables: smd_engine_film_table_floats() floats or NULL */
+int smd_engine_bind_schedule(smd_engine* e, const float* coef, const float* sqrt_ap,
+                             const float* alphas_prod_ext, float* film_tables);
+int smd_engine_refresh_weights(smd_engine* e, void* stream);   /* fp32 master -> bf16 operand pack */
+
+/* nn.Model.__call__: model(x:(B,S,C), noise_level:(B,)) -> eps_hat (models/ncsn.py:141-179, 125-135) */
+int smd_engine_forward(smd_engine* e, const float* x, const float* noise_level, float* eps_out, void* stream);
+
+/* diffusion_loss + value_and_grad (utils/losses.py:250-308, train_ncsn.py:282-283).
+ * labels/eps_in NULL -> on-device Philox draws keyed by (seed, global sample index, step).
+ * inv_global_count = 1 / (global_batch * S * C).  stage 0 = everything, 1 = forward + output-stage
+ * backward (gradients of parameters >= head offset are final), 2 = remaining backward. */
+int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labels, const float* eps_in,
+                             uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset,
+                             float inv_global_count, int stage, void* stream);
+const float* smd_engine_loss_per_sample(const smd_engine* e);   /* [B] device pointer */
+const float* smd_engine_pred(const smd_engine* e);              /* [B*S][C] device pointer */
+
+/* clip_grads + Adam + stepped LR + EMA + bf16 re-cast (train_ncsn.py:284-287,340-342,364-365) */
+typedef struct smd_train_hyper {
+  float lr0, lr_gamma;
+  int32_t lr_interval;
+  float beta1, beta2, eps, grad_clip, mu;
+  float grad_scale;        /* multiplies the gradients first (1/world_size after a SUM all-reduce) */
+} smd_train_hyper;
+int smd_engine_optimizer_step(smd_engine* e, const smd_train_hyper* h, void* stream);
+
+/* diffusion_dynamics (utils/ebm_utils.py:280-405), one sample_with_beta iteration per call */
+typedef struct smd_sample_io {
+  float* x;                        /* [B][S][C] state, in place */
+  int32_t* t_ptr;                  /* device timestep; decremented by the call */
+  const float* z_in;               /* explicit N(0,1) draw or NULL (Philox) */
+  uint32_t seed_lo, seed_hi, sample_offset;
+  const float* infill_samples;     /* NULL unless infilling */
+  const float* infill_masks;
+  const float* infill_z_in;
+  float* metrics_partial;          /* [T][B][3] or NULL */
+  float* collection;               /* [41][B][S][C] or NULL */
+  const int32_t* slot_table;       /* [T] collection slot for timestep t, -1 = none */
+} smd_sample_io;
+int smd_engine_prepare_sampler(smd_engine* e, void* stream);
+int smd_engine_init_state(smd_engine* e, float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset,
+                          void* stream);
+/* explicit initial state (parity mode / infill / interpolation): refreshes the bf16 network input */
+int smd_engine_load_state(smd_engine* e, const float* x, void* stream);
+int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream);
+
+/* ---- single kernels (unit-testable ops) ------------------------------------------------------- */
+enum { SMD_EPI_NONE = 0, SMD_EPI_GELU = 1, SMD_EPI_SWISH = 2 };
+/* C[M,N] = act(A[M,K] Bt[N,K]^T + bias) (+ residual); nn.Dense, models/ncsn.py:155 etc. */
+int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, int M, int N, int K,
+                     const float* bias, int act, const float* residual, int ld_res, float* out_f32, int ld_out,
+                     smd_bf16* out_bf16, int ld_outb, void* stream);
+/* dW[Kd,N] = X[M,Kd]^T dY[M,N] (weight gradient); zero_page: >= 128 zeroed bf16 (tr_path=1) or a
+ * scratch of (Kd+N)*roundup(M,64) bf16 (tr_path=0) */
+int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out,
+                     int ldo, smd_bf16* scratch, int64_t scratch_elems, int tr_path, void* stream);
+/* flax.nn.LayerNorm (+ FiLM + swish), models/shared.py:62-68 */
+int smd_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
+                      const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample,
+                      int swish, smd_bf16* out, void* stream);
+int smd_layernorm_bwd(const float* x, int rows, int D, const float* gamma, const float* beta,
+                      const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample,
+                      int swish, const smd_bf16* dout, float* dx, float* dgamma, float* dbeta, float* dscale,
+                      float* dshift, float* partial, int64_t partial_elems, void* stream);
+/* flax.nn.SelfAttention core, models/ncsn.py:161 */
+int smd_attention_fwd(const smd_bf16* qkv, smd_bf16* out, int B, int S, int E, int H, void* stream);
+int smd_attention_bwd(const smd_bf16* qkv, const smd_bf16* dout, smd_bf16* dqkv, int B, int S, int E, int H,
+                      void* stream);
+/* NoiseEncoding.apply, models/ncsn.py:28-41 */
+int smd_noise_embed(const float* noise_level, int n, int channels, smd_bf16* out, int ld_out, void* stream);
+/* Philox4x32-10 normals: out[b][e], counter (e/4, b + sample_offset, stream_id, 0) */
+int smd_rng_normal(float* out, int B, int per_sample, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
+                   uint32_t sample_offset, void* stream);
+int smd_cast_pad_bf16(const float* in, int rows, int cols, smd_bf16* out, int ld_out, void* stream);
+/* one reverse step on explicit eps_hat (the elementwise part of utils/ebm_utils.py:327-394) */
+int smd_ddpm_reverse_step(float* x, const float* eps_hat, int B, int S, int C, const float* coef,
+                          const int32_t* t_ptr, const float* z_in, uint32_t seed_lo, uint32_t seed_hi,
+                          uint32_t sample_offset, float* metrics_partial, float* collection,
+                          const int32_t* slot_table, void* stream);
+/* lane-level probe of ds_read_b64_tr_b16 (debug): out[64][4] = values read from a 2 KiB linear image */
+int smd_probe_tr_read(const smd_bf16* image_1024, smd_bf16* out_256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMD_HIP_H_ */

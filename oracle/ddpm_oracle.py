@@ -1,0 +1,600 @@
+"""CPU restatement ORACLE of the reference DDPM hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  The product path
+(``symbolic-music-diffusion_amd/``) never imports anything from ``oracle/`` and
+fails loudly when the HIP library is missing.
+
+PARITY UNPINNED.  The reference (magenta/symbolic-music-diffusion @ v1) ships no
+tests, no golden vectors and no fixtures for this path, and its arithmetic lives in
+un-vendored third-party packages that are not installable here (flax==0.3.0,
+jax==0.2.8, jaxlib==0.1.57, requirements.txt:47,94,95).  This restatement follows
+the reference's own call sites line by line and restates the published flax/jax
+layer semantics (the ORACLE_ASSUMPTIONS table below); it is pinned only by the
+closed-form known-answer tests in tests/test_oracle.py.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference repo root).  Arithmetic is torch-CPU; dtype is a parameter (float64 for
+parity checks, float32 for the timed CPU baseline).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+# ----------------------------------------------------------------------------------
+# Third-party semantics restated from flax 0.3.0 / jax 0.2.8 (not in /root/reference).
+# One table so each entry can be flipped if a JAX environment ever contradicts it.
+# ----------------------------------------------------------------------------------
+ORACLE_ASSUMPTIONS = {
+    "dense_kernel_layout": "(in, out); y = x @ kernel + bias",  # flax.nn.Dense
+    "dense_init": "lecun_normal: truncated normal, std = sqrt(1/fan_in)/0.87962566",
+    "layernorm_eps": 1e-6,  # flax.nn.LayerNorm default epsilon
+    "layernorm_var": "biased; E[x^2] - E[x]^2",
+    "attention_q_scaling": "query / sqrt(head_dim) before the logits",
+    "attention_softmax_axis": "keys",
+    "gelu": "tanh approximation",
+    "adam": dict(beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0),
+    "clip_grads": "g * max_norm / norm  iff  norm >= max_norm (global L2 over leaves)",
+    "stepped_lr": "lr0 * gamma**max(0, ceil(step / interval) - 1)",
+    "uniform_minval_gt_maxval": "jax 0.2.8 uniform ends with max(minval, .) -> minval",
+}
+
+LN_EPS = 1e-6
+
+
+# ----------------------------------------------------------------------------------
+# Configuration of the eps-network
+# ----------------------------------------------------------------------------------
+@dataclass
+class NetConfig:
+    """Model kwargs as built at train_ncsn.py:321-326 plus the data shape."""
+    architecture: str = "TransformerDDPM"
+    data_channels: int = 512          # C  (inputs.shape[-1])
+    seq_len: int = 32                 # S  (TransformerDDPM only)
+    num_layers: int = 6               # train_ncsn.py:69
+    num_heads: int = 8                # train_ncsn.py:70
+    num_mlp_layers: int = 2           # train_ncsn.py:71
+    mlp_dims: int = 2048              # train_ncsn.py:72
+    embed_channels: int = 128         # hard-coded, models/ncsn.py:151
+    film_channels: int = 128          # DenseFiLM(t, 128, mlp_dims), models/ncsn.py:174
+
+
+def param_spec(cfg: NetConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Ordered (name, shape) list of every trainable tensor.
+
+    Stable explicit names; shapes are the flax layouts:
+    Dense kernel (in,out); attention q/k/v kernels (E,H,d) are kept flattened and
+    concatenated as (E, 3*H*d) [query | key | value], out kernel (H,d,E) flattened
+    to (H*d, E); FiLM scale/shift Dense kernels concatenated as (4F, 2M)
+    [scale | shift].
+    """
+    C, E, M, F = cfg.data_channels, cfg.embed_channels, cfg.mlp_dims, cfg.film_channels
+    spec: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def dense(name, i, o):
+        spec.append((name + ".kernel", (i, o)))
+        spec.append((name + ".bias", (o,)))
+
+    def ln(name, d):
+        spec.append((name + ".scale", (d,)))
+        spec.append((name + ".bias", (d,)))
+
+    def film_and_res(prefix_f, prefix_r):
+        dense(prefix_f + ".fc1", F, 4 * F)          # models/ncsn.py:53
+        dense(prefix_f + ".fc2", 4 * F, 4 * F)      # models/ncsn.py:55
+        dense(prefix_f + ".ss", 4 * F, 2 * M)       # models/ncsn.py:60-61 (scale|shift)
+        ln(prefix_r + ".ln1", M)                    # models/shared.py:62
+        dense(prefix_r + ".fc1", M, M)              # models/shared.py:65
+        ln(prefix_r + ".ln2", M)                    # models/shared.py:66
+        dense(prefix_r + ".fc2", M, M)              # models/shared.py:69
+
+    if cfg.architecture in ("TransformerDDPM", "TransformerDDPM4"):
+        dense("in_proj", C, E)                      # models/ncsn.py:155
+        for l in range(cfg.num_layers):
+            p = f"enc.{l}"
+            ln(p + ".ln1", E)                       # models/ncsn.py:160
+            dense(p + ".attn.qkv", E, 3 * E)        # models/ncsn.py:161 (SelfAttention)
+            dense(p + ".attn.out", E, E)
+            ln(p + ".ln2", E)                       # models/ncsn.py:164
+            dense(p + ".mlp.fc1", E, M)             # models/ncsn.py:165
+            dense(p + ".mlp.fc2", M, E)             # models/ncsn.py:167
+        ln("ln_f", E)                               # models/ncsn.py:170
+        dense("up", E, M)                           # models/ncsn.py:171
+        for k in range(cfg.num_mlp_layers):
+            film_and_res(f"film.{k}", f"res.{k}")   # models/ncsn.py:173-175
+        ln("ln_o", M)                               # models/ncsn.py:177
+        dense("out_proj", M, C)                     # models/ncsn.py:178
+    elif cfg.architecture == "DenseDDPM":
+        dense("in_proj", C, M)                      # models/ncsn.py:129
+        for k in range(cfg.num_layers):
+            film_and_res(f"film.{k}", f"res.{k}")   # models/ncsn.py:130-132
+        ln("ln_o", M)                               # models/ncsn.py:133
+        dense("out_proj", M, C)                     # models/ncsn.py:134
+    else:
+        raise ValueError(f"unsupported architecture {cfg.architecture}")
+    return spec
+
+
+def num_params(cfg: NetConfig) -> int:
+    return int(sum(int(np.prod(s)) for _, s in param_spec(cfg)))
+
+
+def init_params(cfg: NetConfig, seed: int = 0, dtype=torch.float64) -> Dict[str, torch.Tensor]:
+    """lecun-normal kernels, zero biases, unit LayerNorm scales
+    (ORACLE_ASSUMPTIONS 1/2; reference: train_ncsn.py:193-199 init_by_shape).
+    NumPy default_rng(seed) so the same file can be produced anywhere."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in param_spec(cfg):
+        if name.endswith(".kernel"):
+            fan_in = shape[0]
+            std = math.sqrt(1.0 / fan_in) / 0.87962566103423978
+            # truncated normal on [-2, 2] by rejection (what jax.random.truncated_normal draws)
+            w = rng.standard_normal(size=shape)
+            bad = np.abs(w) > 2.0
+            while bad.any():
+                w[bad] = rng.standard_normal(size=int(bad.sum()))
+                bad = np.abs(w) > 2.0
+            out[name] = torch.from_numpy(w * std).to(dtype)
+        elif name.endswith(".scale"):
+            out[name] = torch.ones(shape, dtype=dtype)
+        else:
+            out[name] = torch.zeros(shape, dtype=dtype)
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# Layers (L0/L1)
+# ----------------------------------------------------------------------------------
+def dense(x, p, name):
+    """flax.nn.Dense: x @ kernel + bias (call sites models/ncsn.py:53-61,155,165-171,178)."""
+    return x @ p[name + ".kernel"] + p[name + ".bias"]
+
+
+def layer_norm(x, p, name):
+    """flax.nn.LayerNorm over the last axis, eps 1e-6, biased variance as E[x^2]-E[x]^2
+    (call sites models/ncsn.py:160,164,170,177; models/shared.py:62,66)."""
+    mean = x.mean(dim=-1, keepdim=True)
+    mean2 = (x * x).mean(dim=-1, keepdim=True)
+    var = mean2 - mean * mean
+    y = (x - mean) * torch.rsqrt(var + LN_EPS)
+    return y * p[name + ".scale"] + p[name + ".bias"]
+
+
+def gelu(x):
+    """flax.nn.gelu (tanh approximation), models/ncsn.py:166."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def swish(x):
+    """flax.nn.swish, models/ncsn.py:54, models/shared.py:64,68."""
+    return x * torch.sigmoid(x)
+
+
+def _sinusoid_freqs(half_dim: int, dtype):
+    # models/shared.py:41-42 == models/ncsn.py:34-35
+    emb = math.log(10000.0) / float(half_dim - 1)
+    return torch.exp(torch.arange(half_dim, dtype=dtype) * -emb)
+
+
+def positional_encoding(seq_len: int, channels: int, dtype=torch.float64):
+    """TransformerPositionalEncoding.apply, models/shared.py:36-48: [sin | cos] halves."""
+    f = _sinusoid_freqs(channels // 2, dtype)
+    emb = torch.arange(seq_len, dtype=dtype)[:, None] * f[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+    if channels % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1))
+    return emb
+
+
+def noise_encoding(noise, channels: int):
+    """NoiseEncoding.apply, models/ncsn.py:28-41. noise: (B,1) noise level sqrt(alpha_bar)."""
+    noise = noise.squeeze(-1)
+    assert noise.dim() == 1
+    f = _sinusoid_freqs(channels // 2, noise.dtype)
+    emb = 5000.0 * noise[:, None] * f[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+    if channels % 2 == 1:
+        emb = torch.nn.functional.pad(emb, (0, 1))
+    return emb
+
+
+def self_attention(x, p, name, num_heads: int):
+    """flax.nn.SelfAttention(x, num_heads) as called at models/ncsn.py:161: no mask, no
+    dropout, qkv_features = out_features = E; q scaled by 1/sqrt(d) before the logits."""
+    B, S, E = x.shape
+    d = E // num_heads
+    qkv = dense(x, p, name + ".qkv")                       # (B,S,3E)  [q | k | v], each (H,d)
+    q, k, v = qkv.split(E, dim=-1)
+    q = q.reshape(B, S, num_heads, d) / math.sqrt(d)
+    k = k.reshape(B, S, num_heads, d)
+    v = v.reshape(B, S, num_heads, d)
+    logits = torch.einsum("bqhd,bkhd->bhqk", q, k)
+    w = torch.softmax(logits, dim=-1)
+    o = torch.einsum("bhqk,bkhd->bqhd", w, v).reshape(B, S, E)
+    return dense(o, p, name + ".out")
+
+
+def dense_film(position, p, name, film_channels: int, mlp_dims: int, sequence: bool):
+    """DenseFiLM.apply, models/ncsn.py:47-61.  Returns (scale, shift)."""
+    assert position.dim() == 2
+    e = noise_encoding(position, film_channels)
+    e = dense(e, p, name + ".fc1")
+    e = swish(e)
+    e = dense(e, p, name + ".fc2")
+    if sequence:
+        e = e[:, None, :]
+    ss = dense(e, p, name + ".ss")
+    return ss[..., :mlp_dims], ss[..., mlp_dims:]
+
+
+def dense_res_block(x, p, name, scale, shift):
+    """DenseResBlock.apply, models/shared.py:61-75 (FeaturewiseAffine :54-55 = scale*x+shift).
+    Input and output widths are equal on this path so the shortcut is the identity (:72-73)."""
+    o = layer_norm(x, p, name + ".ln1")
+    o = swish(scale * o + shift)
+    o = dense(o, p, name + ".fc1")
+    o = layer_norm(o, p, name + ".ln2")
+    o = swish(scale * o + shift)
+    o = dense(o, p, name + ".fc2")
+    return o + x
+
+
+def transformer_ddpm(p, cfg: NetConfig, inputs, t):
+    """TransformerDDPM.apply, models/ncsn.py:141-179. inputs (B,S,C); t (B,1,1)."""
+    B, S, C = inputs.shape
+    E = cfg.embed_channels
+    temb = positional_encoding(S, E, inputs.dtype)[None]          # :152-153
+    x = dense(inputs, p, "in_proj")                               # :155
+    x = x + temb                                                  # :157
+    for l in range(cfg.num_layers):                               # :158-168
+        pre = f"enc.{l}"
+        shortcut = x
+        x = layer_norm(x, p, pre + ".ln1")
+        x = self_attention(x, p, pre + ".attn", cfg.num_heads)
+        x = x + shortcut
+        shortcut2 = x
+        x = layer_norm(x, p, pre + ".ln2")
+        x = dense(x, p, pre + ".mlp.fc1")
+        x = gelu(x)
+        x = dense(x, p, pre + ".mlp.fc2")
+        x = x + shortcut2
+    x = layer_norm(x, p, "ln_f")                                  # :170
+    x = dense(x, p, "up")                                         # :171
+    for k in range(cfg.num_mlp_layers):                           # :173-175
+        scale, shift = dense_film(t.squeeze(-1), p, f"film.{k}", cfg.film_channels,
+                                  cfg.mlp_dims, sequence=True)
+        x = dense_res_block(x, p, f"res.{k}", scale, shift)
+    x = layer_norm(x, p, "ln_o")                                  # :177
+    return dense(x, p, "out_proj")                                # :178
+
+
+def dense_ddpm(p, cfg: NetConfig, inputs, t):
+    """DenseDDPM.apply, models/ncsn.py:125-135. inputs (B,C); t (B,1).  num_heads /
+    num_mlp_layers kwargs passed by train_ncsn.py:321-326 are accepted and ignored."""
+    x = dense(inputs, p, "in_proj")
+    for k in range(cfg.num_layers):
+        scale, shift = dense_film(t, p, f"film.{k}", cfg.film_channels, cfg.mlp_dims,
+                                  sequence=False)
+        x = dense_res_block(x, p, f"res.{k}", scale, shift)
+    x = layer_norm(x, p, "ln_o")
+    return dense(x, p, "out_proj")
+
+
+def make_model(p, cfg: NetConfig) -> Callable:
+    """The nn.Model callable of the reference: model(x, cond) -> eps_hat."""
+    if cfg.architecture == "DenseDDPM":
+        return lambda x, t: dense_ddpm(p, cfg, x, t)
+    return lambda x, t: transformer_ddpm(p, cfg, x, t)
+
+
+# ----------------------------------------------------------------------------------
+# Noise schedule (L2)
+# ----------------------------------------------------------------------------------
+def create_noise_schedule(sigma_begin=1.0, sigma_end=1e-2, L=10, schedule="geometric"):
+    """utils/ebm_utils.py:62-86.  jnp defaults to float32, so the table is float32."""
+    if schedule == "geometric":
+        s = np.exp(np.linspace(np.log(np.float32(sigma_begin)), np.log(np.float32(sigma_end)),
+                               L, dtype=np.float32))
+    elif schedule == "linear":
+        s = np.linspace(np.float32(sigma_begin), np.float32(sigma_end), L, dtype=np.float32)
+    elif schedule == "fibonacci":
+        v = [1e-6, 2e-6]
+        for _ in range(L - 2):
+            v.append(v[-1] + v[-2])
+        s = np.array(v, dtype=np.float32)
+    else:
+        raise ValueError(f"Unsupported schedule: {schedule}")
+    return s.astype(np.float32)
+
+
+def alphas_cumprod(betas: np.ndarray) -> np.ndarray:
+    """alphas_prod = cumprod(1 - betas) in float32 (utils/ebm_utils.py:315-316, losses.py:277-278)."""
+    return np.cumprod((np.float32(1.0) - betas.astype(np.float32)).astype(np.float32),
+                      dtype=np.float32)
+
+
+# ----------------------------------------------------------------------------------
+# Objective (L2): diffusion_loss, utils/losses.py:250-308
+# ----------------------------------------------------------------------------------
+def reduce_fn(x, mode):
+    """utils/losses.py:22-30."""
+    if mode == "none" or mode is None:
+        return x
+    if mode == "sum":
+        return x.sum()
+    if mode == "mean":
+        return x.mean()
+    raise ValueError("Unsupported reduction option.")
+
+
+def used_alphas_from_labels(betas: np.ndarray, labels: np.ndarray) -> np.ndarray:
+    """utils/losses.py:277-286 with the jax-0.2.8 uniform quirk: minval=alphas_prod'[l-1] >
+    maxval=alphas_prod'[l] so uniform(...) returns minval exactly (ORACLE_ASSUMPTIONS)."""
+    ap = np.concatenate([np.ones((1,), np.float32), alphas_cumprod(betas)])
+    return ap[labels - 1]
+
+
+def diffusion_loss(batch, model, betas, labels, eps, reduction="mean"):
+    """utils/losses.py:250-308 with the random draws (labels :272-275, eps :294) passed in
+    explicitly; continuous_noise=True branch (labels in [1, T]).  Conditions on sqrt(alpha)."""
+    B = batch.shape[0]
+    a = torch.from_numpy(used_alphas_from_labels(betas, labels)).to(batch.dtype)
+    a = a.reshape(B, *([1] * (batch.dim() - 1)))
+    perturbed = torch.sqrt(a) * batch + torch.sqrt(1 - a) * eps          # :295-296
+    pred = model(perturbed, torch.sqrt(a))                                # :299-300
+    loss = (eps - pred) ** 2                                              # :304
+    loss = loss.mean(dim=tuple(range(1, loss.dim())))                     # :305
+    assert loss.shape == batch.shape[:1]
+    return reduce_fn(loss, reduction)
+
+
+# ----------------------------------------------------------------------------------
+# Optimisation step (L3): train_ncsn.py:260-288, 340-342; utils/train_utils.py:73-78
+# ----------------------------------------------------------------------------------
+def stepped_lr(lr0: float, step: int, interval: int, gamma: float) -> float:
+    """flax.training.lr_schedule.create_stepped_learning_rate_schedule as used at
+    train_ncsn.py:340-342 with lr_step_schedule=[(i, gamma**i)]: boundaries i*interval,
+    index = sum(boundaries < step)  ->  lr0 * gamma**max(0, ceil(step/interval)-1)."""
+    idx = max(0, int(math.ceil(step / interval)) - 1)
+    return lr0 * (gamma ** idx)
+
+
+@dataclass
+class AdamState:
+    step: int = 0
+    m: Dict[str, torch.Tensor] = field(default_factory=dict)
+    v: Dict[str, torch.Tensor] = field(default_factory=dict)
+
+
+def clip_grads(grads: Dict[str, torch.Tensor], max_norm: float):
+    """jax.experimental.optimizers.clip_grads / l2_norm (train_ncsn.py:284-285).
+    Returns (clipped grads, norm AFTER clipping as logged by the reference)."""
+    norm = torch.sqrt(sum((g * g).sum() for g in grads.values()))
+    if float(norm) < max_norm:
+        out = grads
+    else:
+        out = {k: g * (max_norm / norm) for k, g in grads.items()}
+    norm_after = torch.sqrt(sum((g * g).sum() for g in out.values()))
+    return out, norm_after
+
+
+def adam_update(p: Dict[str, torch.Tensor], g: Dict[str, torch.Tensor], st: AdamState, lr: float,
+                b1=0.9, b2=0.999, eps=1e-8):
+    """flax.optim.Adam.apply_param_gradient (train_ncsn.py:287): t = step+1;
+    m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr * (m/(1-b1^t)) / (sqrt(v/(1-b2^t)) + eps)."""
+    t = st.step + 1
+    new_p = {}
+    for k in p:
+        m = st.m.get(k, torch.zeros_like(p[k]))
+        v = st.v.get(k, torch.zeros_like(p[k]))
+        m = b1 * m + (1 - b1) * g[k]
+        v = b2 * v + (1 - b2) * g[k] * g[k]
+        mhat = m / (1 - b1 ** t)
+        vhat = v / (1 - b2 ** t)
+        new_p[k] = p[k] - lr * mhat / (torch.sqrt(vhat) + eps)
+        st.m[k], st.v[k] = m, v
+    st.step = t
+    return new_p
+
+
+def ema_update(ema: Dict[str, torch.Tensor], p: Dict[str, torch.Tensor], mu: float):
+    """EMAHelper.update, utils/train_utils.py:73-78."""
+    return {k: ema[k] * mu + p[k] * (1 - mu) for k in ema}
+
+
+def train_step(p, cfg: NetConfig, st: AdamState, batch, betas, labels, eps, lr: float,
+               grad_clip: float = 1.0):
+    """train_ncsn.py:260-288: value_and_grad(mean loss) -> clip_grads -> Adam.
+    Returns (new params, metrics{'loss','grad','lr'}, raw grads)."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    loss = diffusion_loss(batch, make_model(leaf, cfg), betas, labels, eps, "mean")
+    loss.backward()
+    grads = {k: v.grad.detach() for k, v in leaf.items()}
+    clipped, norm_after = clip_grads(grads, grad_clip)
+    new_p = adam_update({k: v.detach() for k, v in leaf.items()}, clipped, st, lr)
+    return new_p, {"loss": float(loss), "grad": float(norm_after), "lr": lr}, grads
+
+
+# ----------------------------------------------------------------------------------
+# Reverse sampler (L3): diffusion_dynamics, utils/ebm_utils.py:280-405
+# ----------------------------------------------------------------------------------
+COLLECTION_STEPS = 40   # utils/ebm_utils.py:320
+
+
+def collection_index_table(T: int) -> np.ndarray:
+    """collection_idx = linspace(1, T, 40).astype(int32), utils/ebm_utils.py:324-325 (float32)."""
+    return np.linspace(np.float32(1), np.float32(T), COLLECTION_STEPS,
+                       dtype=np.float32).astype(np.int32)
+
+
+def collection_slot_for_t(T: int, t: int, table: Optional[np.ndarray] = None) -> int:
+    """utils/ebm_utils.py:387-394: image_idx = T - t + 1; slot = index in table + 1, or -1."""
+    table = collection_index_table(T) if table is None else table
+    image_idx = T - t + 1
+    hit = np.nonzero(table == image_idx)[0]
+    if hit.size == 0:
+        return -1
+    return int(np.sum(hit)) + 1   # sum(arange*mask)+1 (duplicates cannot occur for T>=40)
+
+
+def reverse_coefficients(betas: np.ndarray) -> Dict[str, np.ndarray]:
+    """Per-t constants of sample_with_beta, utils/ebm_utils.py:332-358, in float32 like jnp."""
+    f = np.float32
+    betas = betas.astype(np.float32)
+    alphas = (f(1) - betas).astype(np.float32)
+    ap = alphas_cumprod(betas)
+    ap_prev = np.concatenate([np.ones((1,), np.float32), ap[:-1]])
+    sqrt_recip = np.sqrt(f(1) / ap, dtype=np.float32)
+    sqrt_m1 = (np.sqrt(f(1) - ap, dtype=np.float32) * sqrt_recip).astype(np.float32)
+    mu1 = (betas * np.sqrt(ap_prev, dtype=np.float32) / (f(1) - ap)).astype(np.float32)
+    mu2 = ((f(1) - ap_prev) * np.sqrt(alphas, dtype=np.float32) / (f(1) - ap)).astype(np.float32)
+    var = (betas * (f(1) - ap_prev) / (f(1) - ap)).astype(np.float32)
+    var_c = np.maximum(var, f(1e-20)).astype(np.float32)
+    sigma = np.exp(f(0.5) * np.log(var_c, dtype=np.float32), dtype=np.float32)
+    return dict(alpha_prod=ap, sqrt_alpha_prod=np.sqrt(ap, dtype=np.float32),
+                sqrt_one_minus=np.sqrt(f(1) - ap, dtype=np.float32),
+                sqrt_recip=sqrt_recip, sqrt_m1=sqrt_m1, mu1=mu1, mu2=mu2, sigma=sigma)
+
+
+def _norm_metric(v):
+    # utils/ebm_utils.py:381-383: sqrt(sum(v^2, axis=1) + 1e-10).mean()  (axis 1 = sequence axis)
+    return torch.sqrt((v * v).sum(dim=1) + 1e-10).mean()
+
+
+def diffusion_dynamics(model, betas: np.ndarray, init, noises, infill=False,
+                       infill_samples=None, infill_masks=None, infill_noises=None,
+                       t_start: Optional[int] = None, t_stop: int = 0):
+    """utils/ebm_utils.py:280-405 with the per-step normal draws passed in explicitly:
+    ``noises(t)`` returns z_t of init.shape (the reference draws it at :360-362).
+    Returns (state, collection (41,...), ld_metrics (4,T,1)) exactly shaped like the reference.
+    ``t_start/t_stop`` allow short teacher-forced rollouts (default: full T-1 .. 0)."""
+    T = len(betas)
+    dt = init.dtype
+    co = {k: torch.from_numpy(v).to(dt) for k, v in reverse_coefficients(betas).items()}
+    if not infill:
+        infill_samples = torch.zeros_like(init)
+        infill_masks = torch.zeros_like(init)
+    table = collection_index_table(T)
+    start = init * (1 - infill_masks) + infill_samples * infill_masks          # :321
+    collection = torch.zeros((COLLECTION_STEPS + 1, *init.shape), dtype=dt)     # :322
+    collection[0] = start                                                       # :323
+    metrics = torch.zeros((4, T, 1), dtype=dt)
+    state = init
+    t_hi = T - 1 if t_start is None else t_start
+    for i, t in enumerate(range(t_hi, t_stop - 1, -1)):                         # :400-401
+        # infill template :342-348
+        if infill:
+            inz = infill_noises(t)
+            noisy_y = co["sqrt_alpha_prod"][t] * infill_samples + co["sqrt_one_minus"][t] * inz
+            y = noisy_y if t > 0 else infill_samples
+        else:
+            y = infill_samples
+        z = noises(t) if t > 0 else torch.zeros_like(state)                     # :360-363
+        z = z * co["sigma"][t]                                                  # :364
+        cond = (co["sqrt_alpha_prod"][t] * torch.ones((state.shape[0], 1), dtype=dt)).reshape(
+            state.shape[0], *([1] * (state.dim() - 1)))                         # :367-369
+        eps_recon = model(state, cond)                                          # :370
+        recon = co["sqrt_recip"][t] * state - co["sqrt_m1"][t] * eps_recon      # :371
+        recon = torch.clamp(recon, -1.0, 1.0)                                   # :372
+        mu = co["mu1"][t] * recon + co["mu2"][t] * state                        # :373
+        nxt = mu + z                                                            # :374
+        nxt = nxt * (1 - infill_masks) + y * infill_masks                       # :377
+        step = state - nxt                                                      # :380
+        row = T - 1 - t
+        metrics[0, row, 0] = _norm_metric(eps_recon)                            # grad_norm
+        metrics[1, row, 0] = _norm_metric(step)                                 # step_norm
+        metrics[2, row, 0] = co["alpha_prod"][t]
+        metrics[3, row, 0] = _norm_metric(z)                                    # noise_norm
+        slot = collection_slot_for_t(T, t, table)                               # :387-394
+        if slot >= 0:
+            collection[slot] = nxt
+        state = nxt
+    return state, collection, metrics
+
+
+def collate_sampling_metrics(ld_metrics):
+    """utils/ebm_utils.py:408-428."""
+    _, num_sigmas, num_steps = ld_metrics.shape
+    out = [[] for _ in range(num_sigmas)]
+    for i in range(num_sigmas):
+        g, s, a, n = ld_metrics[:, i, :]
+        for j in range(num_steps):
+            out[i].append({"slope": g[j], "step": s[j], "alpha": a[j], "noise": n[j]})
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# Output-side data transforms (host NumPy), input_pipeline.py:36-48,78-110
+# ----------------------------------------------------------------------------------
+def normalize_dataset(batch, data_min, data_max):
+    """input_pipeline.py:36-40."""
+    batch = (batch - data_min) / (data_max - data_min)
+    return 2.0 * batch - 1.0
+
+
+def inverse_data_transform(batch, normalize=True, data_min=0.0, data_max=1.0, slice_idx=None,
+                           dim_weights=None, out_channels=512, filler=None):
+    """input_pipeline.py:78-110 without the PCA branch (pca_ckpt unused by the DDPM configs).
+    The reference fills the non-selected latent dims with an *unseeded* np.random.randn
+    (:102-105); ``filler`` lets a test pass that array so outputs are comparable."""
+    batch = np.asarray(batch)
+    if normalize:
+        batch = (batch + 1.0) / 2.0
+        batch = (data_max - data_min) * batch + data_min
+    if slice_idx is not None:
+        transformed = (np.random.randn(*batch.shape[:-1], out_channels)
+                       if filler is None else np.array(filler, dtype=np.float64, copy=True))
+        transformed[..., slice_idx] = batch
+        batch = transformed
+    if dim_weights is not None:
+        batch = batch / dim_weights
+    return batch
+
+
+# ----------------------------------------------------------------------------------
+# Counter-based RNG used by the engine's throughput mode (NOT the reference's threefry;
+# JAX-compatible streams are a "next" row).  Philox4x32-10, Random123 constants.
+# ----------------------------------------------------------------------------------
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
+
+
+def philox4x32(ctr: np.ndarray, key: np.ndarray, rounds: int = 10) -> np.ndarray:
+    """ctr (...,4) uint32, key (2,) uint32 -> (...,4) uint32."""
+    c = ctr.astype(np.uint32).copy()
+    k0, k1 = np.uint32(key[0]), np.uint32(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(rounds):
+        p0 = _PHILOX_M0 * c[..., 0].astype(np.uint64)
+        p1 = _PHILOX_M1 * c[..., 2].astype(np.uint64)
+        hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), (p0 & mask).astype(np.uint32)
+        hi1, lo1 = (p1 >> np.uint64(32)).astype(np.uint32), (p1 & mask).astype(np.uint32)
+        n0 = hi1 ^ c[..., 1] ^ k0
+        n2 = hi0 ^ c[..., 3] ^ k1
+        c = np.stack([n0, lo1, n2, lo0], axis=-1)
+        with np.errstate(over="ignore"):
+            k0 = np.uint32((int(k0) + int(_PHILOX_W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(_PHILOX_W1)) & 0xFFFFFFFF)
+    return c
+
+
+def philox_uniform01(bits: np.ndarray) -> np.ndarray:
+    """(0,1] float32 from uint32: (bits>>8 + 1) * 2^-24  -- matches csrc/rng.h."""
+    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(1.0)) * np.float32(2.0 ** -24)
+
+
+def philox_normal4(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """4 standard normals per counter via two Box-Muller pairs -- matches csrc/rng.h."""
+    b = philox4x32(ctr, key)
+    u = philox_uniform01(b).astype(np.float64)
+    r0 = np.sqrt(-2.0 * np.log(u[..., 0]))
+    r1 = np.sqrt(-2.0 * np.log(u[..., 2]))
+    a0 = 2.0 * np.pi * u[..., 1]
+    a1 = 2.0 * np.pi * u[..., 3]
+    return np.stack([r0 * np.cos(a0), r0 * np.sin(a0), r1 * np.cos(a1), r1 * np.sin(a1)], axis=-1)

@@ -1,0 +1,74 @@
+"""Builds csrc/*.hip into the in-tree C-ABI shared library ``csrc/libsmd_hip.so`` for gfx950.
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the repo snapshot
+to the GPU box.  Usage: ``python -m smd_amd.build`` or ``build_library()``.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
+SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "diffusion.hip", "optim.hip",
+           "engine.hip", "capi.hip"]
+HEADERS = ["smd_common.h", "smd_kernels.h", "engine.h", "rng.h",
+           os.path.join("..", "..", "include", "smd_hip.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def find_hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def _newest_input() -> float:
+    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def is_stale() -> bool:
+    return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest_input()
+
+
+def build_library(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    hipcc = find_hipcc()
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        srcp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_time):
+            return obj
+        cmd = [hipcc, *FLAGS, "-c", srcp, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    tmp = LIB_PATH + ".tmp"
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(tmp, LIB_PATH)
+    if verbose:
+        print(f"[smd_amd.build] built {LIB_PATH}", file=sys.stderr)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

@@ -1,0 +1,201 @@
+// extern "C" surface of libsmd_hip.so -- see include/smd_hip.h for the contract.
+#include "../../include/smd_hip.h"
+
+#include <new>
+
+#include "engine.h"
+
+const char* smd_get_error();
+
+struct smd_engine {
+  SmdEngine impl;
+  explicit smd_engine(const SmdModelDesc& d) : impl(d) {}
+};
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline const bf16_t* B(const smd_bf16* p) { return reinterpret_cast<const bf16_t*>(p); }
+static inline bf16_t* B(smd_bf16* p) { return reinterpret_cast<bf16_t*>(p); }
+
+#define NEED(e)                                        \
+  do {                                                 \
+    if (!(e)) {                                        \
+      smd_set_error("%s: null engine handle", __func__); \
+      return -1;                                       \
+    }                                                  \
+  } while (0)
+
+extern "C" {
+
+const char* smd_last_error(void) { return smd_get_error(); }
+int smd_abi_version(void) { return SMD_ABI_VERSION; }
+
+int smd_engine_create(const smd_model_desc* d, smd_engine** out) {
+  SMD_ARG_CHECK(d && out, "smd_engine_create: null argument");
+  SMD_ARG_CHECK(d->arch == 0 || d->arch == 1, "smd_engine_create: arch=%d (0 TransformerDDPM, 1 DenseDDPM)", d->arch);
+  SMD_ARG_CHECK(d->data_channels > 0 && d->num_layers > 0 && d->mlp_dims > 0 && d->num_timesteps > 0,
+                "smd_engine_create: non-positive dimension");
+  SMD_ARG_CHECK(d->embed_channels == 128 && d->film_channels == 128,
+                "smd_engine_create: embed/film channels are fixed at 128 (models/ncsn.py:151,174)");
+  SMD_ARG_CHECK(d->mlp_dims % 256 == 0 && d->mlp_dims <= 4096, "smd_engine_create: mlp_dims=%d must be a multiple of 256 <= 4096", d->mlp_dims);
+  if (d->arch == 0) {
+    SMD_ARG_CHECK(d->seq_len == 32, "smd_engine_create: TransformerDDPM kernels are specialised for seq_len 32 (got %d)", d->seq_len);
+    SMD_ARG_CHECK(d->num_heads > 0 && 128 % d->num_heads == 0 && (128 / d->num_heads == 8 || 128 / d->num_heads == 16 || 128 / d->num_heads == 32),
+                  "smd_engine_create: num_heads=%d unsupported (4, 8, 16)", d->num_heads);
+    SMD_ARG_CHECK(d->num_mlp_layers > 0, "smd_engine_create: num_mlp_layers must be positive");
+  } else {
+    SMD_ARG_CHECK(d->seq_len == 1, "smd_engine_create: DenseDDPM takes (B, C) inputs: seq_len must be 1");
+  }
+  SmdModelDesc m;
+  m.arch = d->arch; m.data_channels = d->data_channels; m.seq_len = d->seq_len; m.num_layers = d->num_layers;
+  m.num_heads = d->num_heads; m.num_mlp_layers = d->num_mlp_layers; m.mlp_dims = d->mlp_dims;
+  m.embed_channels = d->embed_channels; m.film_channels = d->film_channels; m.num_timesteps = d->num_timesteps;
+  smd_engine* e = new (std::nothrow) smd_engine(m);
+  SMD_ARG_CHECK(e, "smd_engine_create: out of host memory");
+  *out = e;
+  return 0;
+}
+void smd_engine_destroy(smd_engine* e) { delete e; }
+
+int smd_engine_num_tensors(const smd_engine* e) { return e ? (int)e->impl.tensors().size() : -1; }
+int smd_engine_tensor_info(const smd_engine* e, int i, const char** name, int64_t* offset, int32_t* rows,
+                           int32_t* cols) {
+  NEED(e);
+  SMD_ARG_CHECK(i >= 0 && i < (int)e->impl.tensors().size(), "tensor_info: index %d out of range", i);
+  const TensorInfo& t = e->impl.tensors()[i];
+  if (name) *name = t.name.c_str();
+  if (offset) *offset = t.offset;
+  if (rows) *rows = t.rows;
+  if (cols) *cols = t.cols;
+  return 0;
+}
+int64_t smd_engine_param_count(const smd_engine* e) { return e ? e->impl.param_count() : -1; }
+int64_t smd_engine_head_param_offset(const smd_engine* e) { return e ? e->impl.head_param_offset() : -1; }
+int64_t smd_engine_wpack_elems(const smd_engine* e) { return e ? e->impl.wpack_elems() : -1; }
+int64_t smd_engine_workspace_bytes(const smd_engine* e, int batch, int training) {
+  return (e && batch > 0) ? e->impl.workspace_bytes(batch, training) : -1;
+}
+int64_t smd_engine_film_table_floats(const smd_engine* e) { return e ? e->impl.film_table_floats() : -1; }
+int smd_engine_padded_channels(const smd_engine* e) { return e ? e->impl.padded_channels() : -1; }
+int smd_engine_set_option(smd_engine* e, const char* key, int value) {
+  NEED(e);
+  SMD_ARG_CHECK(key, "set_option: null key");
+  if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
+  smd_set_error("set_option: unknown key '%s'", key);
+  return -1;
+}
+
+int smd_engine_bind_params(smd_engine* e, float* params, smd_bf16* wpack) { NEED(e); return e->impl.bind_params(params, B(wpack)); }
+int smd_engine_bind_train(smd_engine* e, float* grads, float* m, float* v, float* ema, uint32_t* step, float* metrics) {
+  NEED(e);
+  return e->impl.bind_train(grads, m, v, ema, step, metrics);
+}
+int smd_engine_bind_workspace(smd_engine* e, void* ws, int64_t bytes, int batch, int training, void* stream) {
+  NEED(e);
+  return e->impl.bind_workspace(ws, bytes, batch, training, S(stream));
+}
+int smd_engine_bind_schedule(smd_engine* e, const float* coef, const float* sqrt_ap, const float* ape, float* tables) {
+  NEED(e);
+  return e->impl.bind_schedule(coef, sqrt_ap, ape, tables);
+}
+int smd_engine_refresh_weights(smd_engine* e, void* stream) { NEED(e); return e->impl.refresh_weights(S(stream)); }
+int smd_engine_forward(smd_engine* e, const float* x, const float* s, float* out, void* stream) {
+  NEED(e);
+  return e->impl.forward(x, s, out, S(stream));
+}
+int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labels, const float* eps_in,
+                             uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset, float inv_global_count,
+                             int stage, void* stream) {
+  NEED(e);
+  return e->impl.loss_backward(x0, labels, eps_in, seed_lo, seed_hi, sample_offset, inv_global_count, stage, S(stream));
+}
+const float* smd_engine_loss_per_sample(const smd_engine* e) { return e ? e->impl.loss_per_sample() : nullptr; }
+const float* smd_engine_pred(const smd_engine* e) { return e ? e->impl.pred() : nullptr; }
+
+int smd_engine_optimizer_step(smd_engine* e, const smd_train_hyper* h, void* stream) {
+  NEED(e);
+  SMD_ARG_CHECK(h, "optimizer_step: null hyper-parameters");
+  TrainHyper t;
+  t.lr0 = h->lr0; t.lr_gamma = h->lr_gamma; t.lr_interval = h->lr_interval; t.beta1 = h->beta1; t.beta2 = h->beta2;
+  t.eps = h->eps; t.grad_clip = h->grad_clip; t.mu = h->mu; t.grad_scale = h->grad_scale;
+  return e->impl.optimizer_step(t, S(stream));
+}
+int smd_engine_prepare_sampler(smd_engine* e, void* stream) { NEED(e); return e->impl.prepare_sampler(S(stream)); }
+int smd_engine_init_state(smd_engine* e, float* x, uint32_t lo, uint32_t hi, uint32_t off, void* stream) {
+  NEED(e);
+  return e->impl.init_state(x, lo, hi, off, S(stream));
+}
+int smd_engine_load_state(smd_engine* e, const float* x, void* stream) {
+  NEED(e);
+  return e->impl.load_state(x, S(stream));
+}
+int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream) {
+  NEED(e);
+  SMD_ARG_CHECK(io, "sample_step: null io");
+  SampleStepIO s;
+  s.x = io->x; s.t_ptr = io->t_ptr; s.z_in = io->z_in; s.seed_lo = io->seed_lo; s.seed_hi = io->seed_hi;
+  s.sample_offset = io->sample_offset; s.infill_samples = io->infill_samples; s.infill_masks = io->infill_masks;
+  s.infill_z_in = io->infill_z_in; s.metrics_partial = io->metrics_partial; s.collection = io->collection;
+  s.slot_table = io->slot_table;
+  return e->impl.sample_step(s, S(stream));
+}
+
+// ------------------------------------------------------------------ single kernels
+int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, int M, int N, int K, const float* bias,
+                     int act, const float* residual, int ld_res, float* out_f32, int ld_out, smd_bf16* out_bf16,
+                     int ld_outb, void* stream) {
+  GemmEpilogue ep;
+  ep.bias = bias; ep.act = act; ep.res_f32 = residual; ep.ld_res = ld_res;
+  ep.out_f32 = out_f32; ep.ld_out = ld_out; ep.out_bf16 = B(out_bf16); ep.ld_outb = ld_outb;
+  return launch_gemm_nt(B(A), lda, B(Bt), ldb, M, N, K, ep, S(stream));
+}
+int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out, int ldo,
+                     smd_bf16* scratch, int64_t scratch_elems, int tr_path, void* stream) {
+  return launch_gemm_tn(B(X), ldx, B(dY), ldy, M, Kd, N, out, ldo, B(scratch), (size_t)scratch_elems, tr_path, S(stream));
+}
+int smd_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta, const float* film_scale,
+                      const float* film_shift, int ld_film, int rows_per_sample, int swish, smd_bf16* out, void* stream) {
+  LnArgs a;
+  a.x = x; a.rows = rows; a.D = D; a.gamma = gamma; a.beta = beta; a.film_scale = film_scale; a.film_shift = film_shift;
+  a.ld_film = ld_film; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.swish = swish; a.out = B(out);
+  return launch_layernorm_fwd(a, S(stream));
+}
+int smd_layernorm_bwd(const float* x, int rows, int D, const float* gamma, const float* beta, const float* film_scale,
+                      const float* film_shift, int ld_film, int rows_per_sample, int swish, const smd_bf16* dout,
+                      float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, float* partial,
+                      int64_t partial_elems, void* stream) {
+  LnBwdArgs b;
+  b.f.x = x; b.f.rows = rows; b.f.D = D; b.f.gamma = gamma; b.f.beta = beta; b.f.film_scale = film_scale;
+  b.f.film_shift = film_shift; b.f.ld_film = ld_film; b.f.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+  b.f.swish = swish;
+  b.dout = B(dout); b.dx = dx; b.dgamma = dgamma; b.dbeta = dbeta; b.dscale = dscale; b.dshift = dshift;
+  b.partial = partial; b.partial_elems = (size_t)partial_elems;
+  return launch_layernorm_bwd(b, S(stream));
+}
+int smd_attention_fwd(const smd_bf16* qkv, smd_bf16* out, int Bn, int Sn, int E, int H, void* stream) {
+  return launch_attention_fwd(B(qkv), B(out), Bn, Sn, E, H, S(stream));
+}
+int smd_attention_bwd(const smd_bf16* qkv, const smd_bf16* dout, smd_bf16* dqkv, int Bn, int Sn, int E, int H, void* stream) {
+  return launch_attention_bwd(B(qkv), B(dout), B(dqkv), Bn, Sn, E, H, S(stream));
+}
+int smd_noise_embed(const float* s, int n, int channels, smd_bf16* out, int ld_out, void* stream) {
+  return launch_noise_embed(s, n, channels, B(out), ld_out, S(stream));
+}
+int smd_rng_normal(float* out, int Bn, int per_sample, uint32_t lo, uint32_t hi, uint32_t stream_id, uint32_t off, void* stream) {
+  return launch_fill_normal(out, Bn, per_sample, RngKey{lo, hi}, stream_id, off, S(stream));
+}
+int smd_cast_pad_bf16(const float* in, int rows, int cols, smd_bf16* out, int ld_out, void* stream) {
+  return launch_cast_pad_bf16(in, rows, cols, B(out), ld_out, S(stream));
+}
+int smd_ddpm_reverse_step(float* x, const float* eps_hat, int Bn, int Sn, int C, const float* coef, const int32_t* t_ptr,
+                          const float* z_in, uint32_t lo, uint32_t hi, uint32_t off, float* metrics_partial,
+                          float* collection, const int32_t* slot_table, void* stream) {
+  ReverseStepArgs a;
+  a.x = x; a.eps_hat = eps_hat; a.B = Bn; a.S = Sn; a.C = C; a.Cp = C; a.coef = coef; a.t_ptr = t_ptr; a.z_in = z_in;
+  a.key = RngKey{lo, hi}; a.sample_offset = off; a.metrics_partial = metrics_partial; a.collection = collection;
+  a.slot_table = slot_table;
+  return launch_reverse_step(a, S(stream));
+}
+
+int smd_probe_tr_read(const smd_bf16* image, smd_bf16* out, void* stream) { return launch_probe_tr_read(B(image), B(out), S(stream)); }
+
+}  // extern "C"

@@ -1,0 +1,332 @@
+// HBM-bound elementwise kernels of the DDPM objective and reverse sampler.
+//
+//   noise_embed      NoiseEncoding.apply                      models/ncsn.py:28-41
+//   q_sample         labels, alpha lookup, eps, x_t           utils/losses.py:271-296
+//   mse_loss_grad    mean((eps-pred)^2) and d/dpred            utils/losses.py:304-308
+//   reverse_step     one sample_with_beta iteration            utils/ebm_utils.py:327-394
+//
+// All per-step scalars (timestep t, optimiser step) are read from device memory so the whole
+// step is hipGraph-replayable with frozen kernel arguments.
+#include "smd_kernels.h"
+#include "rng.h"
+
+namespace {
+
+// ------------------------------------------------------------------ noise embedding
+__global__ __launch_bounds__(256) void noise_embed_kernel(const float* __restrict__ s, int n, int channels,
+                                                          bf16_t* __restrict__ out, int ld_out) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int half = channels >> 1;
+  if (idx >= n * half) return;
+  const int r = idx / half, i = idx - r * half;
+  // emb = exp(arange(half) * -(log(10000)/(half-1))) ; arg = (5000 * noise) * emb   (fp32, same order)
+  const float f = expf((float)i * -(9.210340371976184f / (float)(half - 1)));
+  const float arg = (5000.0f * s[r]) * f;
+  float sn, cs;
+  sincosf(arg, &sn, &cs);
+  out[(size_t)r * ld_out + i] = f2bf(sn);
+  out[(size_t)r * ld_out + half + i] = f2bf(cs);
+  if ((channels & 1) && i == 0) out[(size_t)r * ld_out + channels - 1] = f2bf(0.0f);
+}
+
+// ------------------------------------------------------------------ q-sample
+__global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
+  const int SC = a.S * a.C;
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int e0 = g * 4;
+  const int b = blockIdx.y;
+  if (e0 >= SC) return;
+  const uint32_t bglob = (uint32_t)b + a.sample_offset;
+  const uint32_t step = a.step_ptr ? *a.step_ptr : 0u;
+  int label;
+  if (a.labels) {
+    label = a.labels[b];
+  } else {
+    const uint4 r = philox4x32_10(make_uint4(0u, bglob, SMD_STREAM_LABEL, step), a.key.seed_lo, a.key.seed_hi);
+    label = 1 + (int)(r.x % (uint32_t)a.T);          // randint[1, T+1), utils/losses.py:272-275
+  }
+  // jax-0.2.8 uniform(minval=ap[l-1], maxval=ap[l]) degenerates to minval
+  const float alpha = a.alphas_prod_ext[label - 1];
+  const float sa = sqrtf(alpha), sb = sqrtf(1.0f - alpha);
+  const size_t base = (size_t)b * SC + e0;
+  float4 eps;
+  if (a.eps_in) eps = *reinterpret_cast<const float4*>(a.eps_in + base);
+  else eps = philox_normal4((uint32_t)g, bglob, SMD_STREAM_EPS, step, a.key.seed_lo, a.key.seed_hi);
+  const float4 x0 = *reinterpret_cast<const float4*>(a.x0 + base);
+  const float xt[4] = {sa * x0.x + sb * eps.x, sa * x0.y + sb * eps.y, sa * x0.z + sb * eps.z,
+                       sa * x0.w + sb * eps.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int e = e0 + i;
+    const int srow = e / a.C, c = e - srow * a.C;
+    a.xt_bf16[((size_t)b * a.S + srow) * a.Cp + c] = f2bf(xt[i]);
+  }
+  *reinterpret_cast<float4*>(a.eps_out + base) = eps;
+  if (g == 0) a.s_out[b] = sa;
+}
+
+// ------------------------------------------------------------------ loss + gradient wrt pred
+__global__ __launch_bounds__(256) void mse_loss_grad_kernel(const float* __restrict__ pred,
+                                                            const float* __restrict__ eps, int S, int C, int Cp,
+                                                            float inv_global_count,
+                                                            float* __restrict__ loss_per_sample,
+                                                            bf16_t* __restrict__ dpred) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, SC = S * C;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < SC; e += 256) {
+    const float d = pred[(size_t)b * SC + e] - eps[(size_t)b * SC + e];
+    acc += d * d;
+    const int srow = e / C, c = e - srow * C;
+    dpred[((size_t)b * S + srow) * Cp + c] = f2bf(2.0f * d * inv_global_count);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) loss_per_sample[b] = (red[0] + red[1] + red[2] + red[3]) / (float)SC;
+}
+
+// ------------------------------------------------------------------ fused reverse step
+template <int VEC> struct VecT;
+template <> struct VecT<4> { typedef float4 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int VEC>
+__device__ __forceinline__ void ldv(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else *p = v[0];
+}
+
+template <int VEC>
+__global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
+  __shared__ float red[2][3];
+  const int b = blockIdx.x;
+  const int t = *a.t_ptr;
+  const float* cf = a.coef + (size_t)t * 8;
+  const float sqrt_recip = cf[0], sqrt_m1 = cf[1], mu1 = cf[2], mu2 = cf[3], sigma = cf[4];
+  const float sqrt_ap = cf[6], sqrt_1m = cf[7];
+  const bool noisy = t > 0;
+  const int slot = a.collection ? a.slot_table[t] : -1;
+  const uint32_t bglob = (uint32_t)b + a.sample_offset;
+  const size_t sample_base = (size_t)b * a.S * a.C;
+  float m_eps = 0.f, m_step = 0.f, m_z = 0.f;
+  for (int col0 = threadIdx.x * VEC; col0 < a.C; col0 += 128 * VEC) {
+    float acc_e[VEC], acc_s[VEC], acc_z[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc_e[v] = acc_s[v] = acc_z[v] = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+      const int e = s * a.C + col0;
+      const size_t idx = sample_base + e;
+      float x[VEC], eh[VEC], z[VEC], nx[VEC];
+      ldv<VEC>(a.x + idx, x);
+      ldv<VEC>(a.eps_hat + idx, eh);
+      if (noisy) {                                               // utils/ebm_utils.py:360-364
+        if (a.z_in) {
+          ldv<VEC>(a.z_in + idx, z);
+        } else {
+          const float4 n4 = philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_Z, (uint32_t)t,
+                                           a.key.seed_lo, a.key.seed_hi);
+          if constexpr (VEC == 4) { z[0] = n4.x; z[1] = n4.y; z[2] = n4.z; z[3] = n4.w; }
+          else z[0] = pick4(n4, e & 3);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) z[v] *= sigma;
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float recon = sqrt_recip * x[v] - sqrt_m1 * eh[v];        // :371
+        recon = fminf(fmaxf(recon, -1.0f), 1.0f);                 // :372
+        nx[v] = mu1 * recon + mu2 * x[v] + z[v];                  // :373-374
+      }
+      if (a.infill_masks) {                                       // :342-348, :377
+        float im[VEC], is[VEC], iz[VEC];
+        ldv<VEC>(a.infill_masks + idx, im);
+        ldv<VEC>(a.infill_samples + idx, is);
+        if (noisy) {
+          if (a.infill_z_in) {
+            ldv<VEC>(a.infill_z_in + idx, iz);
+          } else {
+            const float4 n4 = philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_INFILL, (uint32_t)t,
+                                             a.key.seed_lo, a.key.seed_hi);
+            if constexpr (VEC == 4) { iz[0] = n4.x; iz[1] = n4.y; iz[2] = n4.z; iz[3] = n4.w; }
+            else iz[0] = pick4(n4, e & 3);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float y = noisy ? sqrt_ap * is[v] + sqrt_1m * iz[v] : is[v];
+          nx[v] = nx[v] * (1.0f - im[v]) + y * im[v];
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float st = x[v] - nx[v];
+        acc_e[v] += eh[v] * eh[v];
+        acc_s[v] += st * st;
+        acc_z[v] += z[v] * z[v];
+      }
+      stv<VEC>(a.x + idx, nx);
+      if (slot >= 0) stv<VEC>(a.collection + ((size_t)slot * a.B) * a.S * a.C + idx, nx);
+      if (a.x_bf16) {
+        bf16_t* xb = a.x_bf16 + ((size_t)b * a.S + s) * a.Cp + col0;
+        if constexpr (VEC == 4) {
+          bf16x4_t p;
+#pragma unroll
+          for (int v = 0; v < 4; ++v) p[v] = f2bf(nx[v]);
+          *reinterpret_cast<bf16x4_t*>(xb) = p;
+        } else {
+          xb[0] = f2bf(nx[0]);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {                                // :381-383 (axis=1 is the sequence axis)
+      m_eps += sqrtf(acc_e[v] + 1e-10f);
+      m_step += sqrtf(acc_s[v] + 1e-10f);
+      m_z += sqrtf(acc_z[v] + 1e-10f);
+    }
+  }
+  if (a.metrics_partial) {
+    m_eps = wave_sum(m_eps); m_step = wave_sum(m_step); m_z = wave_sum(m_z);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = m_eps; red[w][1] = m_step; red[w][2] = m_z; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+      a.metrics_partial[((size_t)t * a.B + b) * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];
+  }
+}
+
+__global__ void advance_t_kernel(int* t_ptr) { *t_ptr -= 1; }
+
+__global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restrict__ in, int rows, int cols,
+                                                            bf16_t* __restrict__ out, int ld_out) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)rows * ld_out) return;
+  const int r = (int)(idx / ld_out), c = (int)(idx - (size_t)r * ld_out);
+  out[idx] = c < cols ? f2bf(in[(size_t)r * cols + c]) : f2bf(0.0f);
+}
+
+__global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, int per_sample, RngKey key,
+                                                          uint32_t stream, uint32_t sample_offset) {
+  const int g = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (g * 4 >= per_sample) return;
+  const float4 n = philox_normal4((uint32_t)g, (uint32_t)b + sample_offset, stream, 0u, key.seed_lo, key.seed_hi);
+  *reinterpret_cast<float4*>(out + (size_t)b * per_sample + g * 4) = n;
+}
+
+__global__ __launch_bounds__(256) void swish_bwd_bf16_kernel(const bf16_t* __restrict__ pre,
+                                                             const bf16_t* __restrict__ dout,
+                                                             bf16_t* __restrict__ din, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) din[i] = f2bf(bf2f(dout[i]) * swish_gradf_(bf2f(pre[i])));
+}
+
+}  // namespace
+
+int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_out, hipStream_t st) {
+  SMD_ARG_CHECK(s && out && n > 0 && channels >= 4 && ld_out >= channels, "noise_embed: bad arguments");
+  const int total = n * (channels / 2);
+  hipLaunchKernelGGL(noise_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, st, s, n, channels, out, ld_out);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_q_sample(const QSampleArgs& a, hipStream_t st) {
+  SMD_ARG_CHECK(a.x0 && a.alphas_prod_ext && a.xt_bf16 && a.eps_out && a.s_out, "q_sample: null pointer");
+  SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && a.Cp >= a.C && a.T > 0, "q_sample: bad shape");
+  SMD_ARG_CHECK((a.S * a.C) % 4 == 0, "q_sample: S*C=%d must be a multiple of 4", a.S * a.C);
+  const int groups = a.S * a.C / 4;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((groups + 255) / 256, a.B), dim3(256), 0, st, a);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_mse_loss_grad(const float* pred, const float* eps, int B, int S, int C, int Cp, float inv_global_count,
+                         float* loss_per_sample, bf16_t* dpred_bf16, hipStream_t st) {
+  SMD_ARG_CHECK(pred && eps && loss_per_sample && dpred_bf16 && B > 0 && S > 0 && C > 0 && Cp >= C,
+                "mse_loss_grad: bad arguments");
+  hipLaunchKernelGGL(mse_loss_grad_kernel, dim3(B), dim3(256), 0, st, pred, eps, S, C, Cp, inv_global_count,
+                     loss_per_sample, dpred_bf16);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
+  SMD_ARG_CHECK(a.x && a.eps_hat && a.coef && a.t_ptr, "reverse_step: null pointer");
+  SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && (!a.x_bf16 || a.Cp >= a.C), "reverse_step: bad shape");
+  SMD_ARG_CHECK((a.infill_masks != nullptr) == (a.infill_samples != nullptr), "reverse_step: infill needs samples and masks");
+  SMD_ARG_CHECK(!a.collection || a.slot_table, "reverse_step: collection needs slot_table");
+  if (a.C % 4 == 0 && (!a.x_bf16 || a.Cp % 4 == 0))
+    hipLaunchKernelGGL(reverse_step_kernel<4>, dim3(a.B), dim3(128), 0, st, a);
+  else
+    hipLaunchKernelGGL(reverse_step_kernel<1>, dim3(a.B), dim3(128), 0, st, a);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_advance_t(int* t_ptr, hipStream_t st) {
+  SMD_ARG_CHECK(t_ptr, "advance_t: null pointer");
+  hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(1), 0, st, t_ptr);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cast_pad_bf16(const float* in, int rows, int cols, bf16_t* out, int ld_out, hipStream_t st) {
+  SMD_ARG_CHECK(in && out && rows > 0 && cols > 0 && ld_out >= cols, "cast_pad_bf16: bad arguments");
+  const size_t total = (size_t)rows * ld_out;
+  hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, in, rows, cols,
+                     out, ld_out);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_fill_normal(float* out, int B, int per_sample, RngKey key, uint32_t stream, uint32_t sample_offset,
+                       hipStream_t st) {
+  SMD_ARG_CHECK(out && B > 0 && per_sample > 0 && per_sample % 4 == 0, "fill_normal: per_sample must be a multiple of 4");
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((per_sample / 4 + 255) / 256, B), dim3(256), 0, st, out, per_sample,
+                     key, stream, sample_offset);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_swish_bwd_bf16(const bf16_t* pre, const bf16_t* dout, bf16_t* din, size_t n, hipStream_t st) {
+  SMD_ARG_CHECK(pre && dout && din && n > 0, "swish_bwd: bad arguments");
+  hipLaunchKernelGGL(swish_bwd_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pre, dout, din, n);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// TransformerPositionalEncoding.apply, models/shared.py:36-48: pe[s] = [sin(s f_i) | cos(s f_i)]
+namespace {
+__global__ __launch_bounds__(256) void pos_encoding_kernel(float* __restrict__ pe, int S, int channels) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int half = channels >> 1;
+  if (idx >= S * half) return;
+  const int s = idx / half, i = idx - s * half;
+  const float f = expf((float)i * -(9.210340371976184f / (float)(half - 1)));
+  float sn, cs;
+  sincosf((float)s * f, &sn, &cs);
+  pe[(size_t)s * channels + i] = sn;
+  pe[(size_t)s * channels + half + i] = cs;
+  if ((channels & 1) && i == 0) pe[(size_t)s * channels + channels - 1] = 0.0f;
+}
+}  // namespace
+int launch_pos_encoding(float* pe, int S, int channels, hipStream_t st) {
+  SMD_ARG_CHECK(pe && S > 0 && channels >= 4, "pos_encoding: bad arguments");
+  hipLaunchKernelGGL(pos_encoding_kernel, dim3((S * (channels / 2) + 255) / 256), dim3(256), 0, st, pe, S, channels);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,182 @@
+// Host-side orchestration of the eps-net forward / backward / optimiser / reverse-sampler launches.
+// No device allocation happens here: every buffer is borrowed from the caller (torch's caching
+// allocator on the Python side) and bound through the C-ABI (include/smd_hip.h).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "smd_kernels.h"
+
+struct SmdModelDesc {
+  int arch = 0;              // 0 TransformerDDPM (models/ncsn.py:138-179), 1 DenseDDPM (:122-135)
+  int data_channels = 512;   // C
+  int seq_len = 32;          // S (1 for DenseDDPM)
+  int num_layers = 6;
+  int num_heads = 8;
+  int num_mlp_layers = 2;
+  int mlp_dims = 2048;
+  int embed_channels = 128;  // models/ncsn.py:151
+  int film_channels = 128;   // models/ncsn.py:174
+  int num_timesteps = 1000;
+};
+
+struct TensorInfo {
+  std::string name;
+  int64_t offset;            // element offset in the flat fp32 parameter buffer
+  int rows, cols;            // cols == 0 for 1-D tensors
+};
+
+struct DenseP {              // one nn.Dense: kernel (K,N) + bias (N)
+  int K = 0, N = 0, Kp = 0, Np = 0;
+  int64_t w_off = 0, b_off = 0;        // flat fp32 offsets
+  int64_t W_off = 0, Wt_off = 0;       // bf16 pack offsets: W [K][Np] (dgrad operand), Wt [N][Kp] (forward)
+};
+struct LnP {
+  int D = 0;
+  int64_t g_off = 0, b_off = 0;
+};
+struct EncLayerP { LnP ln1, ln2; DenseP qkv, out, fc1, fc2; };
+struct FilmResP { DenseP f1, f2, ss, r1, r2; LnP ln1, ln2; };
+
+struct TrainHyper {
+  float lr0 = 1e-3f, lr_gamma = 0.98f;
+  int lr_interval = 10000;
+  float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, grad_clip = 1.0f, mu = 0.999f;
+  float grad_scale = 1.0f;
+};
+
+struct SampleStepIO {
+  float* x = nullptr;                 // [B][S][C] fp32 state (in place)
+  int* t_ptr = nullptr;               // device timestep, decremented by the step
+  const float* z_in = nullptr;        // explicit noise or null (Philox)
+  uint32_t seed_lo = 0, seed_hi = 0, sample_offset = 0;
+  const float* infill_samples = nullptr;
+  const float* infill_masks = nullptr;
+  const float* infill_z_in = nullptr;
+  float* metrics_partial = nullptr;   // [T][B][3]
+  float* collection = nullptr;        // [41][B][S][C]
+  const int* slot_table = nullptr;    // [T]
+};
+
+class SmdEngine {
+ public:
+  explicit SmdEngine(const SmdModelDesc& d);
+  const SmdModelDesc& desc() const { return d_; }
+  const std::vector<TensorInfo>& tensors() const { return tensors_; }
+  int64_t param_count() const { return n_params_; }
+  int64_t wpack_elems() const { return n_wpack_; }
+  int64_t head_param_offset() const { return head_off_; }   // params >= this belong to the output stage
+  int64_t workspace_bytes(int batch, int training) const;
+  // K tables [T][2M] fp32 + bf16 scratch for the T-row FiLM generator GEMMs (emb, f1, p)
+  int64_t film_table_floats() const {
+    return (int64_t)nblocks() * d_.num_timesteps * 2 * d_.mlp_dims + (int64_t)d_.num_timesteps * 9 * d_.film_channels / 2 + 64;
+  }
+  int padded_channels() const { return Cp_; }
+
+  int bind_params(float* params, bf16_t* wpack);
+  int bind_train(float* grads, float* m, float* v, float* ema, uint32_t* step_ptr, float* metrics);
+  int bind_workspace(void* ws, int64_t bytes, int batch, int training, hipStream_t st);
+  // coef [T][8] reverse-step constants, sqrt_ap [T], alphas_prod_ext [T+1] = [1, cumprod(1-beta)],
+  // film_tables: film_table_floats() floats (sampling only, may be null for training)
+  int bind_schedule(const float* coef, const float* sqrt_ap, const float* alphas_prod_ext, float* film_tables);
+
+  int refresh_weights(hipStream_t st);                       // fp32 master -> bf16 pack
+  // model(x, cond): x fp32 [B][S][C], noise_level [B] -> eps_hat fp32 [B][S][C]
+  int forward(const float* x, const float* noise_level, float* eps_out, hipStream_t st);
+  // one diffusion_loss forward + backward on the bound batch; stage: 0 = all, 1 = loss+forward+output
+  // stage backward (grads of params >= head_param_offset complete), 2 = stem backward
+  int loss_backward(const float* x0, const int* labels, const float* eps_in, uint32_t seed_lo, uint32_t seed_hi,
+                    uint32_t sample_offset, float inv_global_count, int stage, hipStream_t st);
+  int optimizer_step(const TrainHyper& h, hipStream_t st);
+  int prepare_sampler(hipStream_t st);                       // FiLM tables for every timestep
+  int sample_step(const SampleStepIO& io, hipStream_t st);   // eps-net forward + fused reverse step
+  int init_state(float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset, hipStream_t st);
+  int load_state(const float* x, hipStream_t st);            // explicit state -> bf16 network input
+  // device pointers of a few internals (tests / metrics)
+  const float* loss_per_sample() const { return W.loss; }
+  const float* pred() const { return W.pred; }
+  const float* noise_levels() const { return W.s; }
+  int tr_path = 1;                                            // wgrad: 1 LDS transpose-read kernel, 0 fallback
+
+ private:
+  int nblocks() const { return d_.arch == 0 ? d_.num_mlp_layers : d_.num_layers; }
+  int rows() const { return batch_ * d_.seq_len; }
+  void build_layout();
+  int run_network(const int* t_ptr, hipStream_t st);          // x_bf16 (+ s or table row) -> pred
+  int backward_head(hipStream_t st);
+  int backward_stem(hipStream_t st);
+  int dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmEpilogue ep, hipStream_t st);
+  int dense_bwd(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bf16_t* dX,
+                int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st);
+  float* P(int64_t off) const { return params_ + off; }
+  float* G(int64_t off) const { return grads_ + off; }
+
+  SmdModelDesc d_;
+  std::vector<TensorInfo> tensors_;
+  int64_t n_params_ = 0, n_wpack_ = 0, head_off_ = 0;
+  int Cp_ = 0;
+  // parameter handles
+  DenseP in_proj_, up_, out_proj_;
+  LnP ln_f_, ln_o_;
+  std::vector<EncLayerP> enc_;
+  std::vector<FilmResP> blk_;
+  std::vector<DenseP*> all_dense_;
+
+  // bound buffers
+  float* params_ = nullptr;
+  bf16_t* wpack_ = nullptr;
+  float *grads_ = nullptr, *m_ = nullptr, *v_ = nullptr, *ema_ = nullptr, *metrics_ = nullptr;
+  uint32_t* step_ptr_ = nullptr;
+  const float* coef_ = nullptr;
+  const float* sqrt_ap_ = nullptr;
+  const float* alphas_prod_ext_ = nullptr;
+  float* film_tables_ = nullptr;
+  int batch_ = 0, training_ = 0;
+
+  struct Work {
+    // inputs / outputs of the network
+    bf16_t* x_bf16 = nullptr;     // [R][Cp]
+    float* pe = nullptr;          // [S][E]
+    float* pred = nullptr;        // [R][C]
+    float* s = nullptr;           // [B] noise levels
+    // encoder (index l only in training mode; inference reuses slot 0)
+    std::vector<float*> h, h_mid;         // [R][E]
+    std::vector<bf16_t*> a1, qkv, o, a2, z1, u;
+    float* h_last = nullptr;
+    bf16_t* af = nullptr;
+    // output stage
+    std::vector<float*> y;                // [R][M] trunk (K+1 in training, 1 in inference)
+    std::vector<bf16_t*> ya1, o1, ya2;
+    bf16_t* ao = nullptr;
+    bf16_t* emb = nullptr;                // [B][F]
+    std::vector<bf16_t*> zf1, f1, p;      // [B][4F]
+    std::vector<float*> ss;               // [B][2M]
+    // training
+    float* eps = nullptr;                 // [R][C]
+    float* loss = nullptr;                // [B]
+    bf16_t* dpred = nullptr;              // [R][Cp]
+    float* dy = nullptr;                  // [R][M]
+    bf16_t* dy_bf16 = nullptr;
+    bf16_t* dA_M = nullptr;               // [R][M]
+    bf16_t* do1 = nullptr;                // [R][M]
+    float* dh = nullptr;                  // [R][E]
+    bf16_t* dh_bf16 = nullptr;
+    bf16_t* dA_E = nullptr;               // [R][E]
+    bf16_t* dqkv = nullptr;               // [R][3E]
+    bf16_t* do_ = nullptr;                // [R][E]
+    bf16_t* dz1 = nullptr;                // [R][M]
+    std::vector<float*> dss;              // [B][2M]
+    bf16_t* dss_bf16 = nullptr;           // [B][2M]
+    bf16_t* dp = nullptr;                 // [B][4F]
+    bf16_t* df1 = nullptr;                // [B][4F]
+    float* ln_partial = nullptr;
+    size_t ln_partial_elems = 0;
+    float* colsum_partial = nullptr;
+    size_t colsum_partial_elems = 0;
+    float* norm_partial = nullptr;        // [1024]
+    bf16_t* zero_page = nullptr;          // [128]
+    bf16_t* tn_scratch = nullptr;         // fallback wgrad transposes
+    size_t tn_scratch_elems = 0;
+  } W;
+  int64_t plan(void* base, int batch, int training, Work* w) const;
+};

@@ -1,0 +1,536 @@
+// SmdEngine: launch sequences for the eps-net (reference models/ncsn.py:122-179), the DDPM
+// objective (utils/losses.py:250-308), the optimiser step (train_ncsn.py:260-288) and one
+// reverse-diffusion iteration (utils/ebm_utils.py:327-394).  See engine.h.
+#include "engine.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+// ------------------------------------------------------------------ error string (thread-local)
+static thread_local char g_err[512] = "";
+void smd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* smd_get_error() { return g_err; }
+
+#define RC(x)            \
+  do {                   \
+    int rc__ = (x);      \
+    if (rc__) return rc__; \
+  } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int launch_pos_encoding(float* pe, int S, int channels, hipStream_t st);
+
+// ------------------------------------------------------------------ layout
+SmdEngine::SmdEngine(const SmdModelDesc& d) : d_(d) { build_layout(); }
+
+void SmdEngine::build_layout() {
+  const int C = d_.data_channels, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
+  Cp_ = round_up(C, 64);
+  int64_t off = 0, woff = 0;
+  auto add_dense = [&](const std::string& name, DenseP& p, int K, int N) {
+    p.K = K; p.N = N; p.Kp = round_up(K, 64); p.Np = round_up(N, 64);
+    p.w_off = off; tensors_.push_back({name + ".kernel", off, K, N}); off += (int64_t)K * N;
+    p.b_off = off; tensors_.push_back({name + ".bias", off, N, 0}); off += N;
+    p.W_off = woff; woff += (int64_t)K * p.Np;
+    p.Wt_off = woff; woff += (int64_t)N * p.Kp;
+    woff = (woff + 127) / 128 * 128;
+  };
+  auto add_ln = [&](const std::string& name, LnP& p, int D) {
+    p.D = D;
+    p.g_off = off; tensors_.push_back({name + ".scale", off, D, 0}); off += D;
+    p.b_off = off; tensors_.push_back({name + ".bias", off, D, 0}); off += D;
+  };
+  auto add_block = [&](int k) {
+    FilmResP& b = blk_[k];
+    const std::string f = "film." + std::to_string(k), r = "res." + std::to_string(k);
+    add_dense(f + ".fc1", b.f1, F, 4 * F);
+    add_dense(f + ".fc2", b.f2, 4 * F, 4 * F);
+    add_dense(f + ".ss", b.ss, 4 * F, 2 * M);
+    add_ln(r + ".ln1", b.ln1, M);
+    add_dense(r + ".fc1", b.r1, M, M);
+    add_ln(r + ".ln2", b.ln2, M);
+    add_dense(r + ".fc2", b.r2, M, M);
+  };
+  blk_.resize(nblocks());
+  if (d_.arch == 0) {
+    enc_.resize(d_.num_layers);
+    add_dense("in_proj", in_proj_, C, E);
+    for (int l = 0; l < d_.num_layers; ++l) {
+      const std::string p = "enc." + std::to_string(l);
+      add_ln(p + ".ln1", enc_[l].ln1, E);
+      add_dense(p + ".attn.qkv", enc_[l].qkv, E, 3 * E);
+      add_dense(p + ".attn.out", enc_[l].out, E, E);
+      add_ln(p + ".ln2", enc_[l].ln2, E);
+      add_dense(p + ".mlp.fc1", enc_[l].fc1, E, M);
+      add_dense(p + ".mlp.fc2", enc_[l].fc2, M, E);
+    }
+    head_off_ = off;
+    add_ln("ln_f", ln_f_, E);
+    add_dense("up", up_, E, M);
+  } else {
+    add_dense("in_proj", in_proj_, C, M);
+    head_off_ = off;
+  }
+  for (int k = 0; k < nblocks(); ++k) add_block(k);
+  add_ln("ln_o", ln_o_, M);
+  add_dense("out_proj", out_proj_, M, C);
+  n_params_ = off;
+  n_wpack_ = woff;
+  all_dense_.push_back(&in_proj_);
+  for (auto& e : enc_) { all_dense_.push_back(&e.qkv); all_dense_.push_back(&e.out); all_dense_.push_back(&e.fc1); all_dense_.push_back(&e.fc2); }
+  if (d_.arch == 0) all_dense_.push_back(&up_);
+  for (auto& b : blk_) { all_dense_.push_back(&b.f1); all_dense_.push_back(&b.f2); all_dense_.push_back(&b.ss); all_dense_.push_back(&b.r1); all_dense_.push_back(&b.r2); }
+  all_dense_.push_back(&out_proj_);
+}
+
+// ------------------------------------------------------------------ workspace planner
+namespace {
+struct Carver {
+  char* base;
+  int64_t off = 0;
+  template <typename T> T* take(size_t elems) {
+    off = (off + 255) / 256 * 256;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (int64_t)(elems * sizeof(T));
+    return p;
+  }
+};
+}  // namespace
+
+int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
+  const int S = d_.seq_len, C = d_.data_channels, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
+  const size_t R = (size_t)batch * S, B = (size_t)batch;
+  const int L = d_.arch == 0 ? d_.num_layers : 0, K = nblocks();
+  const int nl = training ? L : (L > 0 ? 1 : 0);   // saved activations per layer only when training
+  const int nk = training ? K : 1;
+  Carver c{reinterpret_cast<char*>(base)};
+  Work t;
+  t.zero_page = c.take<bf16_t>(128);
+  t.x_bf16 = c.take<bf16_t>(R * Cp_);
+  t.pe = c.take<float>((size_t)S * E);
+  t.pred = c.take<float>(R * C);
+  t.s = c.take<float>(B);
+  t.h.resize(nl); t.h_mid.resize(nl); t.a1.resize(nl); t.qkv.resize(nl); t.o.resize(nl);
+  t.a2.resize(nl); t.z1.resize(nl); t.u.resize(nl);
+  for (int l = 0; l < nl; ++l) {
+    t.h[l] = c.take<float>(R * E);
+    t.h_mid[l] = training ? c.take<float>(R * E) : t.h[l];      // inference: residual stream in place
+    t.a1[l] = c.take<bf16_t>(R * E);
+    t.qkv[l] = c.take<bf16_t>(R * 3 * E);
+    t.o[l] = c.take<bf16_t>(R * E);
+    t.a2[l] = training ? c.take<bf16_t>(R * E) : t.a1[l];
+    t.z1[l] = training ? c.take<bf16_t>(R * M) : nullptr;
+    t.u[l] = c.take<bf16_t>(R * M);
+  }
+  if (L > 0) {
+    t.h_last = training ? c.take<float>(R * E) : t.h[0];
+    t.af = c.take<bf16_t>(R * E);
+  }
+  t.y.resize(training ? K + 1 : 1);
+  for (auto& p : t.y) p = c.take<float>(R * M);
+  t.ya1.resize(nk); t.o1.resize(nk); t.ya2.resize(nk);
+  t.zf1.resize(nk); t.f1.resize(nk); t.p.resize(nk); t.ss.resize(nk);
+  for (int k = 0; k < nk; ++k) {
+    t.ya1[k] = c.take<bf16_t>(R * M);
+    t.o1[k] = c.take<bf16_t>(R * M);
+    t.ya2[k] = training ? c.take<bf16_t>(R * M) : t.ya1[k];
+    t.zf1[k] = training ? c.take<bf16_t>(B * 4 * F) : nullptr;
+    t.f1[k] = c.take<bf16_t>(B * 4 * F);
+    t.p[k] = c.take<bf16_t>(B * 4 * F);
+    t.ss[k] = c.take<float>(B * 2 * M);
+  }
+  t.ao = training ? c.take<bf16_t>(R * M) : t.ya1[0];
+  t.emb = c.take<bf16_t>(B * F);
+  if (training) {
+    t.eps = c.take<float>(R * C);
+    t.loss = c.take<float>(B);
+    t.dpred = c.take<bf16_t>(R * Cp_);
+    t.dy = c.take<float>(R * M);
+    t.dy_bf16 = c.take<bf16_t>(R * M);
+    t.dA_M = c.take<bf16_t>(R * M);
+    t.do1 = c.take<bf16_t>(R * M);
+    t.dss.resize(K);
+    for (auto& p : t.dss) p = c.take<float>(B * 2 * M);
+    t.dss_bf16 = c.take<bf16_t>(B * 2 * M);
+    t.dp = c.take<bf16_t>(B * 4 * F);
+    t.df1 = c.take<bf16_t>(B * 4 * F);
+    if (L > 0) {
+      t.dh = c.take<float>(R * E);
+      t.dh_bf16 = c.take<bf16_t>(R * E);
+      t.dA_E = c.take<bf16_t>(R * E);
+      t.dqkv = c.take<bf16_t>(R * 3 * E);
+      t.do_ = c.take<bf16_t>(R * E);
+      t.dz1 = c.take<bf16_t>(R * M);
+    }
+    t.ln_partial_elems = ln_bwd_partial_elems((int)R, M > E ? M : E) / (S >= 32 ? 32 : 1) + 2 * (size_t)M;
+    t.ln_partial = c.take<float>(t.ln_partial_elems);
+    t.colsum_partial_elems = (size_t)64 * (2 * M > 3 * E ? 2 * M : 3 * E);
+    t.colsum_partial = c.take<float>(t.colsum_partial_elems);
+    t.norm_partial = c.take<float>(1024);
+    const size_t Mp = (R + 63) / 64 * 64;
+    t.tn_scratch_elems = tr_path ? 0 : (size_t)2 * (2 * M) * Mp;
+    t.tn_scratch = t.tn_scratch_elems ? c.take<bf16_t>(t.tn_scratch_elems) : nullptr;
+  }
+  if (w) *w = t;
+  return (c.off + 255) / 256 * 256;
+}
+
+int64_t SmdEngine::workspace_bytes(int batch, int training) const { return plan(nullptr, batch, training, nullptr); }
+
+// ------------------------------------------------------------------ binding
+int SmdEngine::bind_params(float* params, bf16_t* wpack) {
+  SMD_ARG_CHECK(params && wpack, "bind_params: null pointer");
+  params_ = params; wpack_ = wpack;
+  return 0;
+}
+int SmdEngine::bind_train(float* grads, float* m, float* v, float* ema, uint32_t* step_ptr, float* metrics) {
+  SMD_ARG_CHECK(grads && m && v && step_ptr && metrics, "bind_train: null pointer");
+  grads_ = grads; m_ = m; v_ = v; ema_ = ema; step_ptr_ = step_ptr; metrics_ = metrics;
+  return 0;
+}
+int SmdEngine::bind_workspace(void* ws, int64_t bytes, int batch, int training, hipStream_t st) {
+  SMD_ARG_CHECK(ws && batch > 0, "bind_workspace: null workspace or batch=%d", batch);
+  const int64_t need = plan(nullptr, batch, training, nullptr);
+  SMD_ARG_CHECK(bytes >= need, "bind_workspace: %lld bytes given, %lld needed", (long long)bytes, (long long)need);
+  plan(ws, batch, training, &W);
+  batch_ = batch; training_ = training;
+  hipError_t e = hipMemsetAsync(ws, 0, (size_t)need, st);   // zero pads / zero page / padded operand columns
+  if (e != hipSuccess) { smd_set_error("bind_workspace: memset: %s", hipGetErrorString(e)); return (int)e; }
+  if (d_.arch == 0) RC(launch_pos_encoding(W.pe, d_.seq_len, d_.embed_channels, st));
+  return 0;
+}
+int SmdEngine::bind_schedule(const float* coef, const float* sqrt_ap, const float* alphas_prod_ext,
+                             float* film_tables) {
+  SMD_ARG_CHECK(coef && sqrt_ap && alphas_prod_ext, "bind_schedule: null pointer");
+  coef_ = coef; sqrt_ap_ = sqrt_ap; alphas_prod_ext_ = alphas_prod_ext; film_tables_ = film_tables;
+  return 0;
+}
+
+int SmdEngine::refresh_weights(hipStream_t st) {
+  SMD_ARG_CHECK(params_ && wpack_, "refresh_weights: parameters not bound");
+  for (DenseP* p : all_dense_)
+    RC(launch_recast_weight(P(p->w_off), p->K, p->N, wpack_ + p->W_off, p->Np, wpack_ + p->Wt_off, p->Kp, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------ dense helpers
+int SmdEngine::dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmEpilogue ep, hipStream_t st) {
+  ep.bias = P(p.b_off);
+  return launch_gemm_nt(A, lda, wpack_ + p.Wt_off, p.Kp, M, p.N, p.Kp, ep, st);
+}
+
+int SmdEngine::dense_bwd(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bf16_t* dX,
+                         int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st) {
+  // dW = X^T dY ; db = colsum(dY) ; dX = dY W^T (* act'(aux))
+  bf16_t* scratch = tr_path ? W.zero_page : W.tn_scratch;
+  const size_t scratch_elems = tr_path ? 128 : W.tn_scratch_elems;
+  RC(launch_gemm_tn(X, ldx, dY, ldy, M, p.K, p.N, G(p.w_off), p.N, scratch, scratch_elems, tr_path, st));
+  RC(launch_colsum_bf16(dY, ldy, M, p.N, G(p.b_off), W.colsum_partial, W.colsum_partial_elems, st));
+  if (dX) {
+    GemmEpilogue ep;
+    ep.out_bf16 = dX; ep.ld_outb = ld_dx;
+    ep.aux = aux; ep.ld_aux = ld_aux; ep.aux_mode = aux_mode;
+    RC(launch_gemm_nt(dY, ldy, wpack_ + p.W_off, p.Np, M, p.K, p.Np, ep, st));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ forward
+int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
+  SMD_ARG_CHECK(params_ && wpack_ && batch_ > 0, "run_network: engine not bound");
+  const int S = d_.seq_len, C = d_.data_channels, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
+  const int R = rows(), B = batch_, K = nblocks();
+  const bool tr = training_ != 0;
+  SMD_ARG_CHECK(!(tr && t_ptr), "run_network: table-driven FiLM is inference only");
+  SMD_ARG_CHECK(!t_ptr || film_tables_, "run_network: sampler tables not bound");
+
+  float* y0 = W.y[0];
+  if (d_.arch == 0) {
+    {  // in_proj + positional encoding (models/ncsn.py:152-157)
+      GemmEpilogue ep;
+      ep.res_f32 = W.pe; ep.ld_res = E; ep.res_row_mod = S;
+      ep.out_f32 = W.h[0]; ep.ld_out = E;
+      RC(dense_fwd(in_proj_, W.x_bf16, Cp_, R, ep, st));
+    }
+    for (int l = 0; l < d_.num_layers; ++l) {   // models/ncsn.py:158-168
+      const int i = tr ? l : 0;
+      float* h_in = W.h[i];
+      float* h_mid = W.h_mid[i];
+      float* h_out = tr ? (l + 1 < d_.num_layers ? W.h[l + 1] : W.h_last) : W.h[0];
+      const EncLayerP& p = enc_[l];
+      LnArgs ln;
+      ln.x = h_in; ln.rows = R; ln.D = E; ln.gamma = P(p.ln1.g_off); ln.beta = P(p.ln1.b_off); ln.out = W.a1[i];
+      RC(launch_layernorm_fwd(ln, st));
+      { GemmEpilogue ep; ep.out_bf16 = W.qkv[i]; ep.ld_outb = 3 * E; RC(dense_fwd(p.qkv, W.a1[i], E, R, ep, st)); }
+      RC(launch_attention_fwd(W.qkv[i], W.o[i], B, S, E, d_.num_heads, st));
+      { GemmEpilogue ep; ep.res_f32 = h_in; ep.ld_res = E; ep.out_f32 = h_mid; ep.ld_out = E;
+        RC(dense_fwd(p.out, W.o[i], E, R, ep, st)); }
+      ln.x = h_mid; ln.gamma = P(p.ln2.g_off); ln.beta = P(p.ln2.b_off); ln.out = W.a2[i];
+      RC(launch_layernorm_fwd(ln, st));
+      { GemmEpilogue ep; ep.act = SMD_ACT_GELU; ep.out_bf16 = W.u[i]; ep.ld_outb = M;
+        if (tr) { ep.pre_bf16 = W.z1[i]; ep.ld_pre = M; }
+        RC(dense_fwd(p.fc1, W.a2[i], E, R, ep, st)); }
+      { GemmEpilogue ep; ep.res_f32 = h_mid; ep.ld_res = E; ep.out_f32 = h_out; ep.ld_out = E;
+        RC(dense_fwd(p.fc2, W.u[i], M, R, ep, st)); }
+    }
+    {  // models/ncsn.py:170-171
+      LnArgs ln;
+      ln.x = W.h_last; ln.rows = R; ln.D = E; ln.gamma = P(ln_f_.g_off); ln.beta = P(ln_f_.b_off); ln.out = W.af;
+      RC(launch_layernorm_fwd(ln, st));
+      GemmEpilogue ep; ep.out_f32 = y0; ep.ld_out = M;
+      RC(dense_fwd(up_, W.af, E, R, ep, st));
+    }
+  } else {  // DenseDDPM stem, models/ncsn.py:129
+    GemmEpilogue ep; ep.out_f32 = y0; ep.ld_out = M;
+    RC(dense_fwd(in_proj_, W.x_bf16, Cp_, R, ep, st));
+  }
+
+  // DenseResBlocks (models/shared.py:61-75) each with its own FiLM generator (models/ncsn.py:47-61,
+  // 173-175 / 130-132).  Per-sample noise levels generate scale/shift here; the sampler reads the
+  // per-timestep tables built by prepare_sampler() instead.
+  if (!t_ptr) RC(launch_noise_embed(W.s, B, F, W.emb, F, st));
+  for (int k = 0; k < K; ++k) {
+    const int i = tr ? k : 0;
+    const FilmResP& b = blk_[k];
+    float* y_in = tr ? W.y[k] : W.y[0];
+    float* y_out = tr ? W.y[k + 1] : W.y[0];
+    const float* scale;
+    const int ld_film = 2 * M;
+    if (t_ptr) {
+      scale = film_tables_ + (size_t)k * d_.num_timesteps * 2 * M;
+    } else {
+      { GemmEpilogue ep; ep.act = SMD_ACT_SWISH; ep.out_bf16 = W.f1[i]; ep.ld_outb = 4 * F;
+        if (tr) { ep.pre_bf16 = W.zf1[i]; ep.ld_pre = 4 * F; }
+        RC(dense_fwd(b.f1, W.emb, F, B, ep, st)); }
+      { GemmEpilogue ep; ep.out_bf16 = W.p[i]; ep.ld_outb = 4 * F; RC(dense_fwd(b.f2, W.f1[i], 4 * F, B, ep, st)); }
+      { GemmEpilogue ep; ep.out_f32 = W.ss[i]; ep.ld_out = 2 * M; RC(dense_fwd(b.ss, W.p[i], 4 * F, B, ep, st)); }
+      scale = W.ss[i];
+    }
+    LnArgs ln;
+    ln.rows = R; ln.D = M; ln.film_scale = scale; ln.film_shift = scale + M; ln.ld_film = ld_film;
+    ln.rows_per_sample = S; ln.t_ptr = t_ptr; ln.swish = 1;
+    ln.x = y_in; ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off); ln.out = W.ya1[i];
+    RC(launch_layernorm_fwd(ln, st));
+    { GemmEpilogue ep; ep.out_bf16 = W.o1[i]; ep.ld_outb = M; RC(dense_fwd(b.r1, W.ya1[i], M, R, ep, st)); }
+    ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off); ln.out = W.ya2[i];
+    RC(launch_layernorm_fwd(ln, st));
+    { GemmEpilogue ep; ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M;
+      RC(dense_fwd(b.r2, W.ya2[i], M, R, ep, st)); }
+  }
+  {  // models/ncsn.py:177-178 / 133-134
+    LnArgs ln;
+    ln.x = tr ? W.y[K] : W.y[0]; ln.rows = R; ln.D = M; ln.gamma = P(ln_o_.g_off); ln.beta = P(ln_o_.b_off);
+    ln.out = W.ao;
+    RC(launch_layernorm_fwd(ln, st));
+    GemmEpilogue ep; ep.out_f32 = W.pred; ep.ld_out = C;
+    RC(dense_fwd(out_proj_, W.ao, M, R, ep, st));
+  }
+  return 0;
+}
+
+int SmdEngine::forward(const float* x, const float* noise_level, float* eps_out, hipStream_t st) {
+  SMD_ARG_CHECK(x && noise_level && eps_out, "forward: null pointer");
+  SMD_ARG_CHECK(batch_ > 0 && !training_, "forward: bind an inference workspace first");
+  const int R = rows(), C = d_.data_channels;
+  RC(launch_cast_pad_bf16(x, R, C, W.x_bf16, Cp_, st));
+  hipError_t e = hipMemcpyAsync(W.s, noise_level, sizeof(float) * batch_, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { smd_set_error("forward: memcpy: %s", hipGetErrorString(e)); return (int)e; }
+  RC(run_network(nullptr, st));
+  e = hipMemcpyAsync(eps_out, W.pred, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { smd_set_error("forward: memcpy: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+// ------------------------------------------------------------------ backward
+static LnArgs ln_args(const float* x, const bf16_t* xb, int rows, const LnP& p, float* params) {
+  LnArgs a;
+  a.x = x; a.x_bf16 = xb; a.rows = rows; a.D = p.D; a.gamma = params + p.g_off; a.beta = params + p.b_off;
+  return a;
+}
+
+int SmdEngine::backward_head(hipStream_t st) {
+  const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
+  const int R = rows(), B = batch_, K = nblocks();
+  // out_proj (models/ncsn.py:178): X = ao, dY = dpred
+  RC(dense_bwd(out_proj_, W.ao, M, W.dpred, Cp_, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st));
+  {
+    LnBwdArgs b;
+    b.f = ln_args(W.y[K], nullptr, R, ln_o_, params_);
+    b.dout = W.dA_M; b.dx = W.dy; b.dx_bf16 = W.dy_bf16;
+    b.dgamma = G(ln_o_.g_off); b.dbeta = G(ln_o_.b_off);
+    b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
+    RC(launch_layernorm_bwd(b, st));
+  }
+  for (int k = K - 1; k >= 0; --k) {
+    const FilmResP& p = blk_[k];
+    // fc2 of the res block: y[k+1] = ya2 W + b + y[k]
+    RC(dense_bwd(p.r2, W.ya2[k], M, W.dy_bf16, M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st));
+    {
+      LnBwdArgs b;
+      b.f = ln_args(nullptr, W.o1[k], R, p.ln2, params_);
+      b.f.film_scale = W.ss[k]; b.f.film_shift = W.ss[k] + M; b.f.ld_film = 2 * M; b.f.rows_per_sample = S;
+      b.f.swish = 1;
+      b.dout = W.dA_M; b.dx_bf16 = W.do1;
+      b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
+      b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 0;
+      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
+      RC(launch_layernorm_bwd(b, st));
+    }
+    RC(dense_bwd(p.r1, W.ya1[k], M, W.do1, M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st));
+    {
+      LnBwdArgs b;
+      b.f = ln_args(W.y[k], nullptr, R, p.ln1, params_);
+      b.f.film_scale = W.ss[k]; b.f.film_shift = W.ss[k] + M; b.f.ld_film = 2 * M; b.f.rows_per_sample = S;
+      b.f.swish = 1;
+      b.dout = W.dA_M; b.dres = W.dy; b.dx = W.dy; b.dx_bf16 = W.dy_bf16;
+      b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
+      b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 1;
+      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
+      RC(launch_layernorm_bwd(b, st));
+    }
+    // FiLM generator (models/ncsn.py:52-61)
+    RC(launch_cast_pad_bf16(W.dss[k], B, 2 * M, W.dss_bf16, 2 * M, st));
+    RC(dense_bwd(p.ss, W.p[k], 4 * F, W.dss_bf16, 2 * M, B, W.dp, 4 * F, nullptr, 0, SMD_AUX_NONE, st));
+    RC(dense_bwd(p.f2, W.f1[k], 4 * F, W.dp, 4 * F, B, W.df1, 4 * F, W.zf1[k], 4 * F, SMD_AUX_SWISH_GRAD, st));
+    RC(dense_bwd(p.f1, W.emb, F, W.df1, 4 * F, B, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st));
+  }
+  if (d_.arch == 0) {
+    // up (models/ncsn.py:171) and ln_f (:170)
+    RC(dense_bwd(up_, W.af, E, W.dy_bf16, M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st));
+    LnBwdArgs b;
+    b.f = ln_args(W.h_last, nullptr, R, ln_f_, params_);
+    b.dout = W.dA_E; b.dx = W.dh; b.dx_bf16 = W.dh_bf16;
+    b.dgamma = G(ln_f_.g_off); b.dbeta = G(ln_f_.b_off);
+    b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
+    RC(launch_layernorm_bwd(b, st));
+  }
+  return 0;
+}
+
+int SmdEngine::backward_stem(hipStream_t st) {
+  const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims;
+  const int R = rows(), B = batch_;
+  if (d_.arch != 0) {
+    return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dy_bf16, M, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st);
+  }
+  for (int l = d_.num_layers - 1; l >= 0; --l) {
+    const EncLayerP& p = enc_[l];
+    // mlp.fc2: h_out = u W2 + b + h_mid ; dz1 = (dh W2^T) * gelu'(z1)
+    RC(dense_bwd(p.fc2, W.u[l], M, W.dh_bf16, E, R, W.dz1, M, W.z1[l], M, SMD_AUX_GELU_GRAD, st));
+    RC(dense_bwd(p.fc1, W.a2[l], E, W.dz1, M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st));
+    {
+      LnBwdArgs b;
+      b.f = ln_args(W.h_mid[l], nullptr, R, p.ln2, params_);
+      b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = W.dh_bf16;
+      b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
+      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
+      RC(launch_layernorm_bwd(b, st));
+    }
+    RC(dense_bwd(p.out, W.o[l], E, W.dh_bf16, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st));
+    RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv, B, S, E, d_.num_heads, st));
+    RC(dense_bwd(p.qkv, W.a1[l], E, W.dqkv, 3 * E, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st));
+    {
+      LnBwdArgs b;
+      b.f = ln_args(W.h[l], nullptr, R, p.ln1, params_);
+      b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = W.dh_bf16;
+      b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
+      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
+      RC(launch_layernorm_bwd(b, st));
+    }
+  }
+  return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dh_bf16, E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st);
+}
+
+int SmdEngine::loss_backward(const float* x0, const int* labels, const float* eps_in, uint32_t seed_lo,
+                             uint32_t seed_hi, uint32_t sample_offset, float inv_global_count, int stage,
+                             hipStream_t st) {
+  SMD_ARG_CHECK(training_ && grads_ && alphas_prod_ext_, "loss_backward: bind a training workspace, the optimiser state and the schedule first");
+  SMD_ARG_CHECK(stage >= 0 && stage <= 2, "loss_backward: stage=%d", stage);
+  const int S = d_.seq_len, C = d_.data_channels;
+  if (stage == 0 || stage == 1) {
+    SMD_ARG_CHECK(x0, "loss_backward: null batch");
+    hipError_t e = hipMemsetAsync(grads_, 0, sizeof(float) * (size_t)n_params_, st);
+    if (e != hipSuccess) { smd_set_error("loss_backward: memset: %s", hipGetErrorString(e)); return (int)e; }
+    QSampleArgs q;
+    q.x0 = x0; q.B = batch_; q.S = S; q.C = C; q.Cp = Cp_; q.T = d_.num_timesteps;
+    q.alphas_prod_ext = alphas_prod_ext_;
+    q.labels = labels; q.eps_in = eps_in; q.key = RngKey{seed_lo, seed_hi};
+    q.step_ptr = step_ptr_; q.sample_offset = sample_offset;
+    q.xt_bf16 = W.x_bf16; q.eps_out = W.eps; q.s_out = W.s;
+    RC(launch_q_sample(q, st));
+    RC(run_network(nullptr, st));
+    RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st));
+    RC(backward_head(st));
+  }
+  if (stage == 0 || stage == 2) RC(backward_stem(st));
+  return 0;
+}
+
+int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {
+  SMD_ARG_CHECK(grads_ && params_, "optimizer_step: not bound");
+  AdamArgs a;
+  a.params = params_; a.grads = grads_; a.m = m_; a.v = v_; a.ema = ema_; a.n = (size_t)n_params_;
+  a.lr0 = h.lr0; a.lr_gamma = h.lr_gamma; a.lr_interval = h.lr_interval;
+  a.beta1 = h.beta1; a.beta2 = h.beta2; a.eps = h.eps; a.grad_clip = h.grad_clip; a.mu = h.mu;
+  a.grad_scale = h.grad_scale;
+  a.step_ptr = step_ptr_; a.norm_partial = W.norm_partial; a.metrics_out = metrics_;
+  RC(launch_grad_sumsq(a, st));
+  RC(launch_adam_clip_ema(a, st));
+  return refresh_weights(st);
+}
+
+// ------------------------------------------------------------------ sampler
+int SmdEngine::prepare_sampler(hipStream_t st) {
+  SMD_ARG_CHECK(film_tables_ && sqrt_ap_, "prepare_sampler: bind_schedule (with film tables) first");
+  // Noise level is batch-uniform inside diffusion_dynamics (utils/ebm_utils.py:367-369): the FiLM
+  // scale/shift of every block depend on t only, so all T rows are generated once here.
+  const int T = d_.num_timesteps, M = d_.mlp_dims, F = d_.film_channels, K = nblocks();
+  float* tables_end = film_tables_ + (size_t)K * T * 2 * M;
+  bf16_t* emb = reinterpret_cast<bf16_t*>(tables_end);
+  bf16_t* f1 = emb + (size_t)T * F;
+  bf16_t* p = f1 + (size_t)T * 4 * F;
+  RC(launch_noise_embed(sqrt_ap_, T, F, emb, F, st));
+  for (int k = 0; k < K; ++k) {
+    const FilmResP& b = blk_[k];
+    { GemmEpilogue ep; ep.act = SMD_ACT_SWISH; ep.out_bf16 = f1; ep.ld_outb = 4 * F; RC(dense_fwd(b.f1, emb, F, T, ep, st)); }
+    { GemmEpilogue ep; ep.out_bf16 = p; ep.ld_outb = 4 * F; RC(dense_fwd(b.f2, f1, 4 * F, T, ep, st)); }
+    { GemmEpilogue ep; ep.out_f32 = film_tables_ + (size_t)k * T * 2 * M; ep.ld_out = 2 * M;
+      RC(dense_fwd(b.ss, p, 4 * F, T, ep, st)); }
+  }
+  return 0;
+}
+
+int SmdEngine::init_state(float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset, hipStream_t st) {
+  SMD_ARG_CHECK(x && batch_ > 0, "init_state: not bound");
+  const int per = d_.seq_len * d_.data_channels;
+  RC(launch_fill_normal(x, batch_, per, RngKey{seed_lo, seed_hi}, /*SMD_STREAM_INIT*/ 3u, sample_offset, st));
+  return launch_cast_pad_bf16(x, rows(), d_.data_channels, W.x_bf16, Cp_, st);
+}
+
+int SmdEngine::load_state(const float* x, hipStream_t st) {
+  SMD_ARG_CHECK(x && batch_ > 0, "load_state: not bound");
+  return launch_cast_pad_bf16(x, rows(), d_.data_channels, W.x_bf16, Cp_, st);
+}
+
+int SmdEngine::sample_step(const SampleStepIO& io, hipStream_t st) {
+  SMD_ARG_CHECK(io.x && io.t_ptr, "sample_step: null state / t pointer");
+  SMD_ARG_CHECK(!training_ && coef_ && film_tables_, "sample_step: bind an inference workspace and the schedule tables first");
+  RC(run_network(io.t_ptr, st));
+  ReverseStepArgs a;
+  a.x = io.x; a.eps_hat = W.pred;
+  a.B = batch_; a.S = d_.seq_len; a.C = d_.data_channels; a.Cp = Cp_; a.T = d_.num_timesteps;
+  a.coef = coef_; a.t_ptr = io.t_ptr; a.z_in = io.z_in; a.key = RngKey{io.seed_lo, io.seed_hi};
+  a.sample_offset = io.sample_offset;
+  a.infill_samples = io.infill_samples; a.infill_masks = io.infill_masks; a.infill_z_in = io.infill_z_in;
+  a.x_bf16 = W.x_bf16; a.metrics_partial = io.metrics_partial; a.collection = io.collection;
+  a.slot_table = io.slot_table;
+  RC(launch_reverse_step(a, st));
+  return launch_advance_t(io.t_ptr, st);
+}

@@ -1,0 +1,316 @@
+// bf16 MFMA weight-gradient GEMM, "TN" form:  dW[Kd,N] (+)= sum_m X[m,Kd] * dY[m,N]
+//
+// Backward of every nn.Dense on the eps-net path (the value_and_grad of train_ncsn.py:282-283).
+// Both operands are stored with the contraction index m as the ROW index, so MFMA fragments
+// (8 consecutive m per lane) need a transposed read.  gfx950 has one: ds_read_b64_tr_b16.
+//
+//   * 128(Kd) x 128(N) output tile, 64 m-rows per K-tile, 4 waves (2x2) x 2x2 MFMA 32x32x16.
+//   * operand tiles [64 m][128 cols] bf16 are DMA'd row-major with global_load_lds_dwordx4
+//     (a 256-B row = 16 lanes), two LDS buffers, counted vmcnt, raw s_barrier (as gemm_nt).
+//   * fragment = two ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of
+//     row (i>>2), 8-byte column chunk (i&3) of a [4 m][16 col] block and receives column i of
+//     those 4 rows (cdna_hip_programming.md section 2 / T10).
+//   * 16-byte chunk c of LDS row r is stored at chunk c ^ ((r&3)<<2) (source-side swizzle +
+//     matching XOR on the read): the 4 rows of one transpose block land in 4 different 64-B
+//     bank quarters, so a 32-lane service group is conflict free.
+//   * split-K over m across blockIdx.y with fp32 atomics when the output has few tiles
+//     (all 128-wide weights); rows past Mrows are sourced from a caller-provided zero page.
+//
+// Fallback (tr_path = 0): explicit bf16 transposes into scratch + the NT kernel.
+#include "smd_kernels.h"
+
+namespace {
+
+constexpr int BT = 128;          // output tile edge (both Kd and N)
+constexpr int BKM = 64;          // m rows per K-tile
+constexpr int TILE_BYTES = BKM * BT * 2;   // 16 KiB
+constexpr int BUF_BYTES = 2 * TILE_BYTES;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef __attribute__((address_space(3))) unsigned char lds_byte_t;
+
+__device__ __forceinline__ void glds16(const bf16_t* g, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+
+union Frag8 {
+  bf16x8_t v;
+  s16x4_t h[2];
+};
+
+// All 8 transpose reads of one k-step + their wait in ONE asm statement (hipcc does not count
+// asm loads; with the builtin form it drains vmcnt(0) -- and with it the prefetched LDS-DMA --
+// before every read).  a0/a1/b0/b1: LDS byte addresses of the two A / two B fragments at
+// k-step 0, row block 0; KOFF = ks*4096 selects the k-step, +1024 the second 4-row block.
+template <int KOFF>
+__device__ __forceinline__ void tr_read_kstep(unsigned a0, unsigned a1, unsigned b0, unsigned b1,
+                                              Frag8 (&af)[2], Frag8 (&bfr)[2]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(af[0].h[0]), "=&v"(af[0].h[1]), "=&v"(af[1].h[0]), "=&v"(af[1].h[1]),
+        "=&v"(bfr[0].h[0]), "=&v"(bfr[0].h[1]), "=&v"(bfr[1].h[0]), "=&v"(bfr[1].h[1])
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "i"(KOFF), "i"(KOFF + 1024)
+      : "memory");
+}
+
+template <int... Es> struct IntSeq {};
+typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
+
+__device__ __forceinline__ void store_one(float a, int row, int col, int Kd, int N, float* out, int ldo,
+                                          int atomic) {
+  if (row < Kd && col < N) {
+    float* o = out + (size_t)row * ldo + col;
+    if (atomic) atomicAdd(o, a);
+    else *o = a;
+  }
+}
+template <int... Es>
+__device__ __forceinline__ void store_tile(const f32x16_t& acc, int row0, int col, int Kd, int N,
+                                           float* out, int ldo, int atomic, IntSeq<Es...>) {
+  (store_one(acc[Es], row0 + (Es & 3) + 8 * (Es >> 2), col, Kd, N, out, ldo, atomic), ...);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
+    const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ dY, int ldy, int Mrows, int Kd,
+    int N, float* __restrict__ out, int ldo, int tiles_n, int ktiles_per_split, int atomic,
+    const bf16_t* __restrict__ zero_page) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+
+  const int tile = blockIdx.x;
+  const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
+  const int kd0 = tk * BT, n0 = tn * BT;
+  const int kt_begin = blockIdx.y * ktiles_per_split;
+  const int total_kt = (Mrows + BKM - 1) / BKM;
+  int kt_end = kt_begin + ktiles_per_split;
+  kt_end = kt_end < total_kt ? kt_end : total_kt;
+  if (kt_begin >= kt_end) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wc = w & 1;
+
+  // ---- DMA sources: wave w piece j covers LDS rows (w*4+j)*4 .. +4 ; 16 lanes per 256-B row.
+  // LDS chunk (lane&15) of row r receives global chunk (lane&15) ^ ((r&3)<<2); r&3 == lane>>4.
+  const int src_chunk = (lane & 15) ^ ((lane >> 4) << 2);
+  int xcol = kd0 + src_chunk * 8;
+  int ycol = n0 + src_chunk * 8;
+  // keep the 16-B read inside the row: columns past the end only feed discarded outputs
+  xcol = xcol + 8 <= ldx ? xcol : 0;
+  ycol = ycol + 8 <= ldy ? ycol : 0;
+  const int piece_row = w * 16 + (lane >> 4);     // + j*4
+
+  auto issue_tile = [&](int kt, int buf) {
+    unsigned char* base = smem + buf * BUF_BYTES + w * 4096;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = kt * BKM + piece_row + j * 4;
+      const bf16_t* src = m < Mrows ? X + (size_t)m * ldx + xcol : zero_page + (lane & 15) * 8;
+      glds16(src, base + j * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = kt * BKM + piece_row + j * 4;
+      const bf16_t* src = m < Mrows ? dY + (size_t)m * ldy + ycol : zero_page + (lane & 15) * 8;
+      glds16(src, base + TILE_BYTES + j * 1024);
+    }
+  };
+
+  // ---- transpose-read addressing (bytes within an operand tile), see header
+  const int g = lane >> 4;                 // 16-lane group
+  const int rsub = (lane >> 2) & 3;        // row within the 4-row transpose block == row & 3
+  const int m_lane = 8 * (g >> 1) + rsub;  // + ks*16 + rd*4
+  int a_col[2], b_col[2];                  // swizzled byte offset within the 256-B row
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ca = (wr * 64 + i * 32 + 16 * (g & 1) + 4 * (lane & 3)) * 2;
+    const int cb = (wc * 64 + i * 32 + 16 * (g & 1) + 4 * (lane & 3)) * 2;
+    a_col[i] = ((((ca >> 4) ^ (rsub << 2)) << 4) | (ca & 15));
+    b_col[i] = ((((cb >> 4) ^ (rsub << 2)) << 4) | (cb & 15)) + TILE_BYTES;
+  }
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)smem;
+  issue_tile(kt_begin, 0);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) {
+      issue_tile(kt + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned tb = lds_base + buf * BUF_BYTES + m_lane * 256;
+    Frag8 af[2], bfr[2];
+#define SMD_TN_KSTEP(KOFF)                                                                      \
+    tr_read_kstep<KOFF>(tb + a_col[0], tb + a_col[1], tb + b_col[0], tb + b_col[1], af, bfr);   \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bfr[j].v, acc[i][j], 0, 0, 0);
+    SMD_TN_KSTEP(0)
+    SMD_TN_KSTEP(4096)
+    SMD_TN_KSTEP(8192)
+    SMD_TN_KSTEP(12288)
+#undef SMD_TN_KSTEP
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const int kh = lane >> 5;
+  store_tile(acc[0][0], kd0 + wr * 64 + 4 * kh, n0 + wc * 64 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
+  store_tile(acc[0][1], kd0 + wr * 64 + 4 * kh, n0 + wc * 64 + 32 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
+  store_tile(acc[1][0], kd0 + wr * 64 + 32 + 4 * kh, n0 + wc * 64 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
+  store_tile(acc[1][1], kd0 + wr * 64 + 32 + 4 * kh, n0 + wc * 64 + 32 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
+}
+
+// ---- bf16 transpose through LDS: out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int ld_in,
+                                                             int rows, int cols, bf16_t* __restrict__ out,
+                                                             int ld_out) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ld_in + c] : (bf16_t)0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < ld_out) out[(size_t)c * ld_out + r] = r < rows ? tile[tx][i] : (bf16_t)0.0f;
+  }
+}
+
+// ---- column sums (bias gradients), two deterministic stages
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const bf16_t* __restrict__ dY, int ldy, int rows,
+                                                            int cols, int rows_per_chunk,
+                                                            float* __restrict__ partial) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int r_begin = blockIdx.y * rows_per_chunk;
+  int r_end = r_begin + rows_per_chunk;
+  r_end = r_end < rows ? r_end : rows;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int r = r_begin; r < r_end; ++r) s += bf2f(dY[(size_t)r * ldy + c]);
+  partial[(size_t)blockIdx.y * cols + c] = s;
+}
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ partial, int nchunks,
+                                                            int cols, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * cols + c];
+  out[c] = s;
+}
+
+}  // namespace
+
+int launch_transpose_bf16(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out,
+                          hipStream_t st) {
+  SMD_ARG_CHECK(in && out && rows > 0 && cols > 0 && ld_in >= cols && ld_out >= rows,
+                "transpose_bf16: bad arguments");
+  dim3 grid((cols + 63) / 64, (ld_out + 63) / 64);
+  hipLaunchKernelGGL(transpose_bf16_kernel, grid, dim3(256), 0, st, in, ld_in, rows, cols, out, ld_out);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out, float* partial,
+                       size_t partial_elems, hipStream_t st) {
+  SMD_ARG_CHECK(dY && out && partial && rows > 0 && cols > 0, "colsum_bf16: bad arguments");
+  int nchunks = (rows + 255) / 256;
+  if (nchunks > 64) nchunks = 64;
+  const int rows_per_chunk = (rows + nchunks - 1) / nchunks;
+  nchunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  SMD_ARG_CHECK(partial_elems >= (size_t)nchunks * cols, "colsum_bf16: workspace too small");
+  dim3 grid((cols + 255) / 256, nchunks);
+  hipLaunchKernelGGL(colsum_stage1_kernel, grid, dim3(256), 0, st, dY, ldy, rows, cols, rows_per_chunk,
+                     partial);
+  SMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, partial, nchunks,
+                     cols, out);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// tr_path: scratch[0..128) must be a ZEROED page on entry (source for rows past Mrows); the
+// launcher never writes it.
+int launch_gemm_tn(const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int Mrows, int Kd, int N,
+                   float* out, int ldo, bf16_t* scratch, size_t scratch_elems, int tr_path,
+                   hipStream_t st) {
+  SMD_ARG_CHECK(X && dY && out, "gemm_tn: null operand");
+  SMD_ARG_CHECK(Mrows > 0 && Kd > 0 && N > 0, "gemm_tn: bad shape");
+  SMD_ARG_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= 8 && ldy >= 8, "gemm_tn: ldx/ldy must be multiples of 8");
+  if (tr_path) {
+    SMD_ARG_CHECK(scratch && scratch_elems >= 128, "gemm_tn: needs a 128-element zero page in scratch");
+    const int tiles_k = (Kd + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
+    const int tiles = tiles_k * tiles_n;
+    const int total_kt = (Mrows + BKM - 1) / BKM;
+    int nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > total_kt) nsplit = total_kt;
+    if (nsplit < 1) nsplit = 1;
+    const int per = (total_kt + nsplit - 1) / nsplit;
+    nsplit = (total_kt + per - 1) / per;
+    if (nsplit > 1) {
+      hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)N * 4, Kd, st);
+      if (e != hipSuccess) { smd_set_error("gemm_tn: memset2d: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    hipLaunchKernelGGL(gemm_tn_128x128_kernel, dim3(tiles, nsplit), dim3(256), 0, st, X, ldx, dY, ldy,
+                       Mrows, Kd, N, out, ldo, tiles_n, per, nsplit > 1 ? 1 : 0, scratch);
+    SMD_LAUNCH_CHECK();
+    return 0;
+  }
+  // ---- fallback: explicit transposed copies, then the NT kernel (contraction = Mrows padded to 64)
+  const int Mp = (Mrows + 63) / 64 * 64;
+  SMD_ARG_CHECK(scratch && scratch_elems >= (size_t)(Kd + N) * Mp, "gemm_tn: scratch too small for fallback");
+  bf16_t* Xt = scratch;
+  bf16_t* Yt = scratch + (size_t)Kd * Mp;
+  int rc = launch_transpose_bf16(X, ldx, Mrows, Kd, Xt, Mp, st);
+  if (rc) return rc;
+  rc = launch_transpose_bf16(dY, ldy, Mrows, N, Yt, Mp, st);
+  if (rc) return rc;
+  GemmEpilogue ep;
+  ep.out_f32 = out;
+  ep.ld_out = ldo;
+  return launch_gemm_nt(Xt, Mp, Yt, Mp, Kd, N, Mp, ep, st);
+}
+
+// ---- debug probe: what does ds_read_b64_tr_b16 return for a linear image with lane address lane*8 ?
+namespace {
+__global__ void probe_tr_read_kernel(const bf16_t* __restrict__ image, bf16_t* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) bf16_t img[1024];
+  for (int i = threadIdx.x; i < 1024; i += 64) img[i] = image[i];
+  __syncthreads();
+  const unsigned addr = (unsigned)(size_t)(lds_byte_t*)img + threadIdx.x * 8;
+  s16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  union { s16x4_t s; bf16x4_t b; } u;
+  u.s = v;
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = u.b[j];
+}
+}  // namespace
+int launch_probe_tr_read(const bf16_t* image, bf16_t* out, hipStream_t st) {
+  SMD_ARG_CHECK(image && out, "probe_tr_read: null pointer");
+  hipLaunchKernelGGL(probe_tr_read_kernel, dim3(1), dim3(64), 0, st, image, out);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}

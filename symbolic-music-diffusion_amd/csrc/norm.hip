@@ -1,0 +1,322 @@
+// LayerNorm (+ FiLM featurewise affine + swish) forward / backward, wave64 row reductions.
+//
+// Reference semantics: flax.nn.LayerNorm (eps 1e-6, biased variance E[x^2]-E[x]^2) as called at
+// models/ncsn.py:160,164,170,177 and models/shared.py:62,66; FeaturewiseAffine scale*x+shift
+// (models/shared.py:54-55) and nn.swish (models/shared.py:64,68).
+//
+// HBM-bound elementwise work: one wave owns one row (D/64 values per lane held in registers,
+// 16-byte loads), statistics by xor-shuffle reductions, bf16 output written as 8-byte packs.
+#include "smd_kernels.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-6f;
+
+// lane owns elements  v*256 + lane*4 + {0..3}  for v < NV  (D = NV*256), or lane*2+{0,1} for D=128
+template <int D> struct RowLayout {
+  static constexpr int NV = D / 256;
+  static constexpr int PER_LANE = NV * 4;
+  __device__ static int col(int lane, int i) { return (i >> 2) * 256 + lane * 4 + (i & 3); }
+};
+template <> struct RowLayout<128> {
+  static constexpr int NV = 0;
+  static constexpr int PER_LANE = 2;
+  __device__ static int col(int lane, int i) { return lane * 2 + i; }
+};
+
+template <int D>
+__device__ __forceinline__ void load_row(const float* xf, const bf16_t* xb, size_t row, int lane,
+                                         float (&v)[RowLayout<D>::PER_LANE]) {
+  typedef RowLayout<D> L;
+  if constexpr (D == 128) {
+    if (xf) {
+      const float2 t = *reinterpret_cast<const float2*>(xf + row * D + lane * 2);
+      v[0] = t.x; v[1] = t.y;
+    } else {
+      const bf16x2_t t = *reinterpret_cast<const bf16x2_t*>(xb + row * D + lane * 2);
+      v[0] = bf2f(t[0]); v[1] = bf2f(t[1]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+      const size_t off = row * D + k * 256 + lane * 4;
+      if (xf) {
+        const float4 t = *reinterpret_cast<const float4*>(xf + off);
+        v[k * 4 + 0] = t.x; v[k * 4 + 1] = t.y; v[k * 4 + 2] = t.z; v[k * 4 + 3] = t.w;
+      } else {
+        const bf16x4_t t = *reinterpret_cast<const bf16x4_t*>(xb + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[k * 4 + e] = bf2f(t[e]);
+      }
+    }
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void load_vec(const float* p, int lane, float (&v)[RowLayout<D>::PER_LANE]) {
+  load_row<D>(p, nullptr, 0, lane, v);
+}
+
+template <int D>
+__device__ __forceinline__ void store_row_bf16(bf16_t* out, size_t row, int lane,
+                                               const float (&v)[RowLayout<D>::PER_LANE]) {
+  typedef RowLayout<D> L;
+  if constexpr (D == 128) {
+    bf16x2_t t; t[0] = f2bf(v[0]); t[1] = f2bf(v[1]);
+    *reinterpret_cast<bf16x2_t*>(out + row * D + lane * 2) = t;
+  } else {
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k) {
+      bf16x4_t t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = f2bf(v[k * 4 + e]);
+      *reinterpret_cast<bf16x4_t*>(out + row * D + k * 256 + lane * 4) = t;
+    }
+  }
+}
+template <int D>
+__device__ __forceinline__ void store_row_f32(float* out, size_t row, int lane,
+                                              const float (&v)[RowLayout<D>::PER_LANE]) {
+  typedef RowLayout<D> L;
+  if constexpr (D == 128) {
+    *reinterpret_cast<float2*>(out + row * D + lane * 2) = make_float2(v[0], v[1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < L::NV; ++k)
+      *reinterpret_cast<float4*>(out + row * D + k * 256 + lane * 4) =
+          make_float4(v[k * 4 + 0], v[k * 4 + 1], v[k * 4 + 2], v[k * 4 + 3]);
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void row_stats(const float (&x)[RowLayout<D>::PER_LANE], float& mean, float& rstd) {
+  float s = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < RowLayout<D>::PER_LANE; ++i) { s += x[i]; s2 += x[i] * x[i]; }
+  s = wave_sum(s);
+  s2 = wave_sum(s2);
+  mean = s * (1.0f / D);
+  const float var = s2 * (1.0f / D) - mean * mean;
+  rstd = rsqrtf(var + LN_EPS);
+}
+
+// ------------------------------------------------------------------------------ forward
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(LnArgs a) {
+  typedef RowLayout<D> L;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  float x[L::PER_LANE], g[L::PER_LANE], b[L::PER_LANE];
+  load_row<D>(a.x, a.x_bf16, row, lane, x);
+  load_vec<D>(a.gamma, lane, g);
+  load_vec<D>(a.beta, lane, b);
+  float mean, rstd;
+  row_stats<D>(x, mean, rstd);
+  float y[L::PER_LANE];
+#pragma unroll
+  for (int i = 0; i < L::PER_LANE; ++i) y[i] = (x[i] - mean) * rstd * g[i] + b[i];
+  if (a.film_scale) {
+    const int frow = a.t_ptr ? *a.t_ptr : row / a.rows_per_sample;
+    float sc[L::PER_LANE], sh[L::PER_LANE];
+    load_vec<D>(a.film_scale + (size_t)frow * a.ld_film, lane, sc);
+    load_vec<D>(a.film_shift + (size_t)frow * a.ld_film, lane, sh);
+#pragma unroll
+    for (int i = 0; i < L::PER_LANE; ++i) y[i] = sc[i] * y[i] + sh[i];
+  }
+  if (a.swish) {
+#pragma unroll
+    for (int i = 0; i < L::PER_LANE; ++i) y[i] = swishf_(y[i]);
+  }
+  store_row_bf16<D>(a.out, row, lane, y);
+}
+
+// ------------------------------------------------------------------------------ backward
+// One workgroup = one row group (a sample's rows_per_sample rows when FiLM is on, else 32 rows);
+// wave w walks rows w, w+4, ... ; per-column sums live in registers and are combined through LDS.
+struct LnBwdDev {
+  LnArgs f;
+  const bf16_t* dout;
+  const float* dres;      // optional fp32 residual gradient added to dx (may alias dx_f32)
+  float* dx_f32;
+  bf16_t* dx_bf16;
+  float* dscale;
+  float* dshift;
+  int dfilm_accumulate;
+  float* partial;         // [ngroups][2][D]
+  int group_rows;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdDev a) {
+  typedef RowLayout<D> L;
+  constexpr int PL = L::PER_LANE;
+  __shared__ float red[4][D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int grp = blockIdx.x;
+  const int r_begin = grp * a.group_rows;
+  int r_end = r_begin + a.group_rows;
+  r_end = r_end < a.f.rows ? r_end : a.f.rows;
+  const bool film = a.f.film_scale != nullptr;
+
+  float g[PL], b[PL], sc[PL], sh[PL];
+  load_vec<D>(a.f.gamma, lane, g);
+  load_vec<D>(a.f.beta, lane, b);
+  if (film) {
+    const int frow = a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample;
+    load_vec<D>(a.f.film_scale + (size_t)frow * a.f.ld_film, lane, sc);
+    load_vec<D>(a.f.film_shift + (size_t)frow * a.f.ld_film, lane, sh);
+  }
+  float acc_dg[PL], acc_db[PL], acc_dsc[PL], acc_dsh[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) acc_dg[i] = acc_db[i] = acc_dsc[i] = acc_dsh[i] = 0.f;
+
+  for (int row = r_begin + w; row < r_end; row += 4) {
+    float x[PL], dy[PL];
+    load_row<D>(a.f.x, a.f.x_bf16, row, lane, x);
+    load_row<D>(nullptr, a.dout, row, lane, dy);
+    float mean, rstd;
+    row_stats<D>(x, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+    float xh[PL], dxh[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {
+      xh[i] = (x[i] - mean) * rstd;
+      const float n = xh[i] * g[i] + b[i];
+      float d = dy[i];
+      if (film) {
+        const float pre = sc[i] * n + sh[i];
+        if (a.f.swish) d *= swish_gradf_(pre);
+        acc_dsc[i] += d * n;
+        acc_dsh[i] += d;
+        d *= sc[i];
+      } else if (a.f.swish) {
+        d *= swish_gradf_(n);
+      }
+      acc_dg[i] += d * xh[i];
+      acc_db[i] += d;
+      dxh[i] = d * g[i];
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
+    }
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+    float dx[PL];
+#pragma unroll
+    for (int i = 0; i < PL; ++i) dx[i] = rstd * (dxh[i] - s1 - xh[i] * s2);
+    if (a.dres) {
+      float r[PL];
+      load_row<D>(a.dres, nullptr, row, lane, r);
+#pragma unroll
+      for (int i = 0; i < PL; ++i) dx[i] += r[i];
+    }
+    if (a.dx_f32) store_row_f32<D>(a.dx_f32, row, lane, dx);
+    if (a.dx_bf16) store_row_bf16<D>(a.dx_bf16, row, lane, dx);
+  }
+
+  // ---- combine the 4 waves' column sums through LDS, one quantity at a time
+  auto combine = [&](float (&v)[PL], float* dst, int accumulate) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PL; ++i) red[w][L::col(lane, i)] = v[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      if (dst) dst[c] = accumulate ? dst[c] + s : s;
+    }
+  };
+  combine(acc_dg, a.partial + ((size_t)grp * 2 + 0) * D, 0);
+  combine(acc_db, a.partial + ((size_t)grp * 2 + 1) * D, 0);
+  if (film && a.dscale) {
+    const int srow = r_begin / a.f.rows_per_sample;
+    combine(acc_dsc, a.dscale + (size_t)srow * a.f.ld_film, a.dfilm_accumulate);
+    combine(acc_dsh, a.dshift + (size_t)srow * a.f.ld_film, a.dfilm_accumulate);
+  }
+}
+
+// dgamma[c] += sum_g partial[g][0][c] ; dbeta likewise (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int ngroups, int D,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * D) return;
+  const int which = c / D, cc = c - which * D;
+  float s = 0.f;
+  for (int gidx = 0; gidx < ngroups; ++gidx) s += partial[((size_t)gidx * 2 + which) * D + cc];
+  float* dst = which ? dbeta : dgamma;
+  dst[cc] += s;
+}
+
+int ln_group_rows(const LnArgs& f) { return f.film_scale ? f.rows_per_sample : 32; }
+
+}  // namespace
+
+size_t ln_bwd_partial_elems(int rows, int D) {
+  // worst case group size 1 (DenseDDPM: one FiLM row per sample)
+  return (size_t)rows * 2 * D;
+}
+
+static int check_ln(const LnArgs& a, bool need_out) {
+  SMD_ARG_CHECK((a.x != nullptr) != (a.x_bf16 != nullptr), "layernorm: exactly one of x / x_bf16");
+  SMD_ARG_CHECK(a.gamma && a.beta && (a.out || !need_out), "layernorm: null gamma/beta/out");
+  SMD_ARG_CHECK(a.rows > 0, "layernorm: rows=%d", a.rows);
+  SMD_ARG_CHECK((a.film_scale != nullptr) == (a.film_shift != nullptr), "layernorm: scale/shift must come together");
+  if (a.film_scale) {
+    SMD_ARG_CHECK(a.rows_per_sample > 0 && a.rows % a.rows_per_sample == 0 && a.ld_film >= a.D,
+                  "layernorm: bad FiLM geometry rows=%d rows_per_sample=%d ld_film=%d", a.rows,
+                  a.rows_per_sample, a.ld_film);
+  }
+  return 0;
+}
+
+#define SMD_LN_DISPATCH(D_, KERNEL, ...)                                                     \
+  switch (D_) {                                                                              \
+    case 128: KERNEL<128> __VA_ARGS__; break;                                                \
+    case 256: KERNEL<256> __VA_ARGS__; break;                                                \
+    case 512: KERNEL<512> __VA_ARGS__; break;                                                \
+    case 1024: KERNEL<1024> __VA_ARGS__; break;                                              \
+    case 2048: KERNEL<2048> __VA_ARGS__; break;                                              \
+    case 4096: KERNEL<4096> __VA_ARGS__; break;                                              \
+    default: smd_set_error("layernorm: unsupported width D=%d (128,256,512,1024,2048,4096)", D_); return -1; \
+  }
+
+template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_fwd_kernel<D>, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
+}
+template <int D> static void run_bwd(const LnBwdDev& d, int ngroups, hipStream_t st) {
+  hipLaunchKernelGGL(layernorm_bwd_kernel<D>, dim3(ngroups), dim3(256), 0, st, d);
+}
+
+int launch_layernorm_fwd(const LnArgs& a, hipStream_t st) {
+  int rc = check_ln(a, true);
+  if (rc) return rc;
+  SMD_LN_DISPATCH(a.D, run_fwd, (a, st));
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
+  int rc = check_ln(a.f, false);
+  if (rc) return rc;
+  SMD_ARG_CHECK(a.dout && a.partial && a.dgamma && a.dbeta, "layernorm_bwd: null dout/partial/dgamma/dbeta");
+  SMD_ARG_CHECK(a.dx || a.dx_bf16, "layernorm_bwd: no dx output");
+  const int gr = ln_group_rows(a.f);
+  const int ngroups = (a.f.rows + gr - 1) / gr;
+  SMD_ARG_CHECK(a.partial_elems >= (size_t)ngroups * 2 * a.f.D, "layernorm_bwd: workspace too small");
+  LnBwdDev d;
+  d.f = a.f;
+  d.dout = a.dout;
+  d.dres = a.dres;
+  d.dx_f32 = a.dx;
+  d.dx_bf16 = a.dx_bf16;
+  d.dscale = a.dscale;
+  d.dshift = a.dshift;
+  d.dfilm_accumulate = a.dfilm_accumulate;
+  d.partial = a.partial;
+  d.group_rows = gr;
+  SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st));
+  SMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.f.D + 255) / 256), dim3(256), 0, st, a.partial, ngroups,
+                     a.f.D, a.dgamma, a.dbeta);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,180 @@
+// Fused multi-tensor optimiser over the flat fp32 parameter buffer (HBM-bound, 28 B/param):
+//   pass 1  grad_sumsq        per-block partial sums of g^2 (global L2 norm, deterministic order)
+//   pass 2  adam_clip_ema     clip_grads + Adam + stepped LR + EMA in one sweep
+//   pass 3  recast_weights    fp32 master -> bf16 GEMM operand copies in both layouts
+//
+// Reference: jax.experimental.optimizers.clip_grads / l2_norm and flax.optim.Adam as used at
+// train_ncsn.py:284-287; stepped LR schedule train_ncsn.py:340-342; EMAHelper.update
+// utils/train_utils.py:73-78.  The step counter lives in device memory: the LR, the Adam bias
+// correction and the RNG stream offset are all derived from it on device (graph-replayable).
+#include "smd_kernels.h"
+
+namespace {
+
+constexpr int MAX_NORM_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, size_t n,
+                                                         float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4 * 4)) {
+    const float v = g[n4 * 4 + threadIdx.x];
+    acc += v * v;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct AdamDev {
+  float* p; const float* g; float* m; float* v; float* ema;
+  size_t n;
+  float lr0, lr_gamma; int lr_interval;
+  float beta1, beta2, eps, grad_clip, mu, grad_scale;
+  const uint32_t* step_ptr;
+  const float* norm_partial; int norm_blocks;
+  float* metrics_out;
+};
+
+__global__ __launch_bounds__(256) void adam_clip_ema_kernel(AdamDev a) {
+  __shared__ float red[4];
+  __shared__ float s_norm;
+  // every block reduces the (<=1024) partials itself, in the same order: identical norm everywhere
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < a.norm_blocks; i += 256) acc += a.norm_partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) s_norm = sqrtf(red[0] + red[1] + red[2] + red[3]) * a.grad_scale;
+  __syncthreads();
+  const float norm = s_norm;
+  // clip_grads: where(norm < max_norm, g, g * max_norm / norm)
+  const float gmul = a.grad_scale * (norm < a.grad_clip ? 1.0f : a.grad_clip / norm);
+  const uint32_t step = *a.step_ptr;
+  // stepped schedule: lr0 * gamma ** max(0, ceil(step/interval) - 1)
+  const int idx = (int)((step + (uint32_t)a.lr_interval - 1u) / (uint32_t)a.lr_interval) - 1;
+  const float lr = a.lr0 * powf(a.lr_gamma, (float)(idx > 0 ? idx : 0));
+  const float tt = (float)(step + 1u);
+  const float bc1 = 1.0f - powf(a.beta1, tt), bc2 = 1.0f - powf(a.beta2, tt);
+  const float inv_bc1 = 1.0f / bc1, inv_bc2 = 1.0f / bc2;
+  const float ob1 = 1.0f - a.beta1, ob2 = 1.0f - a.beta2, omu = 1.0f - a.mu;
+
+  const size_t n4 = a.n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 p = reinterpret_cast<float4*>(a.p)[i];
+    const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    float4 m = reinterpret_cast<float4*>(a.m)[i];
+    float4 v = reinterpret_cast<float4*>(a.v)[i];
+    float* pp = &p.x; const float* gg = &g.x; float* mm = &m.x; float* vv = &v.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gg[k] * gmul;
+      mm[k] = a.beta1 * mm[k] + ob1 * gk;
+      vv[k] = a.beta2 * vv[k] + ob2 * gk * gk;
+      pp[k] -= lr * (mm[k] * inv_bc1) / (sqrtf(vv[k] * inv_bc2) + a.eps);
+    }
+    reinterpret_cast<float4*>(a.p)[i] = p;
+    reinterpret_cast<float4*>(a.m)[i] = m;
+    reinterpret_cast<float4*>(a.v)[i] = v;
+    if (a.ema) {
+      float4 e = reinterpret_cast<float4*>(a.ema)[i];
+      e.x = e.x * a.mu + p.x * omu; e.y = e.y * a.mu + p.y * omu;
+      e.z = e.z * a.mu + p.z * omu; e.w = e.w * a.mu + p.w * omu;
+      reinterpret_cast<float4*>(a.ema)[i] = e;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(a.n - n4 * 4)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float gk = a.g[i] * gmul;
+    const float m = a.beta1 * a.m[i] + ob1 * gk, v = a.beta2 * a.v[i] + ob2 * gk * gk;
+    const float p = a.p[i] - lr * (m * inv_bc1) / (sqrtf(v * inv_bc2) + a.eps);
+    a.m[i] = m; a.v[i] = v; a.p[i] = p;
+    if (a.ema) a.ema[i] = a.ema[i] * a.mu + p * omu;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.metrics_out) {
+    a.metrics_out[0] = norm;
+    a.metrics_out[1] = norm < a.grad_clip ? norm : a.grad_clip;   // l2_norm of the clipped grads
+    a.metrics_out[2] = lr;
+    a.metrics_out[3] = (float)step;
+  }
+}
+
+__global__ void bump_step_kernel(uint32_t* step_ptr) { *step_ptr += 1u; }
+
+// one (K_in, N_out) fp32 kernel -> W [K_in][ldw] (same orientation) and Wt [N_out][ldwt]
+__global__ __launch_bounds__(256) void recast_weight_kernel(const float* __restrict__ w, int K_in, int N_out,
+                                                            bf16_t* __restrict__ W, int ldw,
+                                                            bf16_t* __restrict__ Wt, int ldwt) {
+  __shared__ float tile[64][65];
+  const int k0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int k = k0 + i, n = n0 + tx;
+    float v = 0.f;
+    if (k < K_in && n < N_out) {
+      v = w[(size_t)k * N_out + n];
+      if (W) W[(size_t)k * ldw + n] = f2bf(v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (Wt) {
+    for (int i = ty; i < 64; i += 4) {
+      const int n = n0 + i, k = k0 + tx;
+      if (n < N_out && k < K_in) Wt[(size_t)n * ldwt + k] = f2bf(tile[tx][i]);
+    }
+  }
+}
+
+}  // namespace
+
+static int norm_blocks_for(size_t n) {
+  size_t b = (n / 4 + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > MAX_NORM_BLOCKS) b = MAX_NORM_BLOCKS;
+  return (int)b;
+}
+
+int launch_grad_sumsq(const AdamArgs& a, hipStream_t st) {
+  SMD_ARG_CHECK(a.grads && a.norm_partial && a.n > 0, "grad_sumsq: bad arguments");
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(norm_blocks_for(a.n)), dim3(256), 0, st, a.grads, a.n, a.norm_partial);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam_clip_ema(const AdamArgs& a, hipStream_t st) {
+  SMD_ARG_CHECK(a.params && a.grads && a.m && a.v && a.step_ptr && a.norm_partial && a.n > 0,
+                "adam_clip_ema: null pointer");
+  SMD_ARG_CHECK(a.lr_interval > 0, "adam_clip_ema: lr_interval must be positive");
+  AdamDev d;
+  d.p = a.params; d.g = a.grads; d.m = a.m; d.v = a.v; d.ema = a.ema; d.n = a.n;
+  d.lr0 = a.lr0; d.lr_gamma = a.lr_gamma; d.lr_interval = a.lr_interval;
+  d.beta1 = a.beta1; d.beta2 = a.beta2; d.eps = a.eps; d.grad_clip = a.grad_clip; d.mu = a.mu;
+  d.grad_scale = a.grad_scale;
+  d.step_ptr = a.step_ptr; d.norm_partial = a.norm_partial; d.norm_blocks = norm_blocks_for(a.n);
+  d.metrics_out = a.metrics_out;
+  size_t blocks = (a.n / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_clip_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d);
+  SMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, st, a.step_ptr);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_recast_weight(const float* w, int K_in, int N_out, bf16_t* W, int ldw, bf16_t* Wt, int ldwt,
+                         hipStream_t st) {
+  SMD_ARG_CHECK(w && (W || Wt) && K_in > 0 && N_out > 0, "recast_weight: bad arguments");
+  SMD_ARG_CHECK((!W || ldw >= N_out) && (!Wt || ldwt >= K_in), "recast_weight: leading dimension too small");
+  hipLaunchKernelGGL(recast_weight_kernel, dim3((N_out + 63) / 64, (K_in + 63) / 64), dim3(256), 0, st, w, K_in,
+                     N_out, W, ldw, Wt, ldwt);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,74 @@
+// Shared device/host helpers for the smd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define SMD_WAVE 64
+
+// ---- error convention (include/smd_hip.h): 0 ok, <0 argument error, >0 hipError_t ----
+void smd_set_error(const char* fmt, ...);
+#define SMD_ARG_CHECK(cond, ...)                         \
+  do {                                                   \
+    if (!(cond)) {                                       \
+      smd_set_error(__VA_ARGS__);                        \
+      return -1;                                         \
+    }                                                    \
+  } while (0)
+#define SMD_LAUNCH_CHECK()                                                     \
+  do {                                                                         \
+    hipError_t e__ = hipGetLastError();                                        \
+    if (e__ != hipSuccess) {                                                   \
+      smd_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e__));  \
+      return (int)e__;                                                         \
+    }                                                                          \
+  } while (0)
+
+// ---- scalar math ----
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float swish_gradf_(float x) {
+  float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+// tanh-approximation GELU (flax.nn.gelu), reference models/ncsn.py:166
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); safe for large |x|
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+__device__ __forceinline__ float geluf_(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf_(u));
+}
+__device__ __forceinline__ float gelu_gradf_(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = tanhf_(u);
+  float du = k0 * (1.0f + 3.0f * k1 * x * x);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+// ---- wave64 reductions (DPP/bpermute via __shfl_xor) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,183 @@
+// Internal C++ launcher interface of the smd HIP library (not part of the C-ABI).
+// Every launcher enqueues on `st`, touches only caller-owned device memory and returns the
+// library error convention (0 ok, <0 argument error, >0 hipError_t).
+#pragma once
+#include "smd_common.h"
+
+// ------------------------------------------------------------------ GEMM (gemm_nt.hip / gemm_tn.hip)
+enum { SMD_ACT_NONE = 0, SMD_ACT_GELU = 1, SMD_ACT_SWISH = 2 };
+enum { SMD_AUX_NONE = 0, SMD_AUX_GELU_GRAD = 1, SMD_AUX_SWISH_GRAD = 2 };
+
+// Epilogue applied to the fp32 accumulator tile, in this order:
+//   v = alpha*acc + bias[col]; pre_bf16 <- v; v = act(v); v *= aux'(aux[row][col]);
+//   v += res_f32[row % res_row_mod][col] (+ res_bf16); out_f32 (= or +=) v; out_bf16 <- v
+struct GemmEpilogue {
+  float alpha = 1.0f;
+  const float* bias = nullptr;       // [N]
+  int act = SMD_ACT_NONE;
+  bf16_t* pre_bf16 = nullptr;        // [M][ld_pre]  value before the activation (training: saved z)
+  int ld_pre = 0;
+  const bf16_t* aux = nullptr;       // [M][ld_aux]  pre-activation whose act'() multiplies (dgrad)
+  int ld_aux = 0;
+  int aux_mode = SMD_AUX_NONE;
+  const float* res_f32 = nullptr;    // [*][ld_res]
+  int ld_res = 0;
+  int res_row_mod = 0;               // >0: residual row = row % res_row_mod (positional table)
+  const bf16_t* res_bf16 = nullptr;  // [M][ld_resb]
+  int ld_resb = 0;
+  float* out_f32 = nullptr;          // [M][ld_out]
+  int ld_out = 0;
+  int accumulate = 0;                // out_f32 += v instead of =
+  bf16_t* out_bf16 = nullptr;        // [M][ld_outb]
+  int ld_outb = 0;
+};
+
+// C[M,N] = A[M,K] * Bt[N,K]^T   (both operands K-contiguous bf16; K % 64 == 0; lda,ldb % 8 == 0)
+int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
+                   const GemmEpilogue& ep, hipStream_t st);
+
+// dW[Kd,N] (+)= sum_m X[m,Kd] * dY[m,N]   (wgrad; both operands row index = contraction index m)
+// X [Mrows][ldx] bf16, dY [Mrows][ldy] bf16, out fp32 [Kd][ldo]. Mrows % 32 == 0.
+// accumulate=0 requires the output to be zeroed by the caller when split-K > 1 (the launcher
+// zeroes it itself with a memset node).  `tr_path`: 1 = LDS transpose-read kernel, 0 = explicit
+// transposed copies through `scratch` (>= (Kd+N)*Mrows bf16) and the NT kernel.
+int launch_gemm_tn(const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int Mrows, int Kd, int N,
+                   float* out, int ldo, bf16_t* scratch, size_t scratch_elems, int tr_path,
+                   hipStream_t st);
+int launch_transpose_bf16(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out,
+                          hipStream_t st);
+// out[n] = sum_m dY[m][n]  (bias gradient), deterministic two-stage reduction via `partial`
+int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out, float* partial,
+                       size_t partial_elems, hipStream_t st);
+
+// ------------------------------------------------------------------ normalisation (norm.hip)
+// y = LN(x) * gamma + beta ; optional FiLM (scale*y + shift per sample) and swish; bf16 out.
+// x is fp32 [rows][D] (ldx = D).  film_scale/shift: [rows/rows_per_sample][ld_film] fp32 or null.
+// If t_ptr != null the FiLM row is *t_ptr for every sample (batch-uniform sampling tables).
+struct LnArgs {
+  const float* x = nullptr;
+  const bf16_t* x_bf16 = nullptr;    // alternative bf16 input (exactly one of x / x_bf16)
+  int rows = 0, D = 0;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  const float* film_scale = nullptr;
+  const float* film_shift = nullptr;
+  int ld_film = 0;
+  int rows_per_sample = 1;
+  const int* t_ptr = nullptr;
+  int swish = 0;
+  bf16_t* out = nullptr;             // [rows][D]
+};
+int launch_layernorm_fwd(const LnArgs& a, hipStream_t st);
+
+// Backward of the same op.  dout bf16 [rows][D] is the gradient wrt `out`.
+//   dx = LN-backward(dout) + (dres ? dres : 0), written as fp32 (dx) and/or bf16 (dx_bf16);
+//   dres may alias dx (in-place residual-gradient stream).
+//   dgamma/dbeta (+=, the flat gradient buffer is zeroed once per step) via per-group partials
+//   in `partial`; dscale/dshift (fp32 [nsamples][ld_film]) = or += per-sample sums over the
+//   sample's rows (the two FiLM uses inside one DenseResBlock share scale/shift).
+struct LnBwdArgs {
+  LnArgs f;                          // the forward arguments (x, gamma, beta, film, swish); f.out unused
+  const bf16_t* dout = nullptr;
+  const float* dres = nullptr;
+  float* dx = nullptr;
+  bf16_t* dx_bf16 = nullptr;
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+  float* dscale = nullptr;
+  float* dshift = nullptr;
+  int dfilm_accumulate = 0;
+  float* partial = nullptr;          // workspace >= ln_bwd_partial_elems(rows, D)
+  size_t partial_elems = 0;
+};
+size_t ln_bwd_partial_elems(int rows, int D);
+int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st);
+
+// ------------------------------------------------------------------ attention (attention.hip)
+// qkv bf16 [B*S][3E] ([q|k|v], head h at cols h*d..), out bf16 [B*S][E]; S == 32, d in {8,16,32}
+int launch_attention_fwd(const bf16_t* qkv, bf16_t* out, int B, int S, int E, int H, hipStream_t st);
+int launch_attention_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int B, int S, int E,
+                         int H, hipStream_t st);
+
+// ------------------------------------------------------------------ diffusion elementwise (diffusion.hip)
+// sinusoidal noise embedding, reference models/ncsn.py:28-41: s[n] -> bf16 [n][channels]
+int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_out, hipStream_t st);
+
+struct RngKey { uint32_t seed_lo, seed_hi; };
+
+// q-sample (reference utils/losses.py:271-296).  x0 fp32 [B][S*C]; tables on device.
+struct QSampleArgs {
+  const float* x0 = nullptr;
+  int B = 0, S = 0, C = 0, Cp = 0;       // Cp: padded row length of xt_bf16
+  int T = 0;
+  const float* alphas_prod_ext = nullptr; // [T+1] = [1, cumprod(1-beta)]
+  const int* labels = nullptr;            // [B] explicit labels in [1,T] or null -> Philox
+  const float* eps_in = nullptr;          // explicit eps or null -> Philox
+  RngKey key{0, 0};
+  const uint32_t* step_ptr = nullptr;     // device step counter (RNG stream offset), may be null
+  uint32_t sample_offset = 0;             // global index of sample 0 (data-parallel shard offset)
+  bf16_t* xt_bf16 = nullptr;              // [B*S][Cp] zero padded
+  float* eps_out = nullptr;               // [B*S][C]
+  float* s_out = nullptr;                 // [B] sqrt(alpha) noise level
+};
+int launch_q_sample(const QSampleArgs& a, hipStream_t st);
+
+// loss + dpred: loss_b = mean_{s,c} (eps-pred)^2 ; dpred = 2 (pred-eps) / (Bglobal*S*C) -> bf16 [B*S][Cp]
+int launch_mse_loss_grad(const float* pred, const float* eps, int B, int S, int C, int Cp,
+                         float inv_global_count, float* loss_per_sample, bf16_t* dpred_bf16,
+                         hipStream_t st);
+
+// fused reverse step (reference utils/ebm_utils.py:327-394)
+struct ReverseStepArgs {
+  float* x = nullptr;                 // [B][S][C] state, updated in place
+  const float* eps_hat = nullptr;     // [B][S][C]
+  int B = 0, S = 0, C = 0, Cp = 0, T = 0;
+  const float* coef = nullptr;        // [T][8]: sqrt_recip, sqrt_m1, mu1, mu2, sigma, alpha_prod, sqrt_ap, sqrt_1m
+  const int* t_ptr = nullptr;         // device timestep
+  const float* z_in = nullptr;        // explicit N(0,1) draw [B][S][C] or null -> Philox
+  RngKey key{0, 0};
+  uint32_t sample_offset = 0;
+  const float* infill_samples = nullptr;  // [B][S][C] or null
+  const float* infill_masks = nullptr;
+  const float* infill_z_in = nullptr;
+  bf16_t* x_bf16 = nullptr;           // [B*S][Cp] next network input (zero padded)
+  float* metrics_partial = nullptr;   // [T][B][3] (grad, step, noise) sums over c of sqrt(sum_s v^2 + 1e-10)
+  float* collection = nullptr;        // [41][B][S][C] or null
+  const int* slot_table = nullptr;    // [T] slot for timestep t or -1
+};
+int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st);
+int launch_advance_t(int* t_ptr, hipStream_t st);   // *t_ptr -= 1
+
+// fp32 [rows][cols] -> bf16 [rows][ld_out] zero padded
+int launch_cast_pad_bf16(const float* in, int rows, int cols, bf16_t* out, int ld_out, hipStream_t st);
+// Philox standard normals (for init state), element e of sample b -> counter (b+sample_offset, e/4)
+int launch_fill_normal(float* out, int B, int per_sample, RngKey key, uint32_t stream,
+                       uint32_t sample_offset, hipStream_t st);
+
+// ------------------------------------------------------------------ optimiser (optim.hip)
+struct AdamArgs {
+  float* params = nullptr;            // fp32 master [n]
+  const float* grads = nullptr;
+  float* m = nullptr;
+  float* v = nullptr;
+  float* ema = nullptr;               // may be null
+  size_t n = 0;
+  float lr0 = 1e-3f, lr_gamma = 0.98f;
+  int lr_interval = 10000;
+  float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, grad_clip = 1.0f, mu = 0.999f;
+  float grad_scale = 1.0f;            // applied to grads before everything (1/world for DP sum)
+  uint32_t* step_ptr = nullptr;       // device step counter, incremented by the kernel tail
+  float* norm_partial = nullptr;      // workspace [>= 1024]
+  float* metrics_out = nullptr;       // [4]: grad norm before clip, after clip, lr, step
+};
+int launch_grad_sumsq(const AdamArgs& a, hipStream_t st);
+int launch_adam_clip_ema(const AdamArgs& a, hipStream_t st);
+
+// master fp32 kernel (K_in, N_out) -> bf16 W [Kp][ldw] (zero padded) and Wt [N_out][ldwt]
+int launch_recast_weight(const float* w, int K_in, int N_out, bf16_t* W, int ldw, bf16_t* Wt, int ldwt,
+                         hipStream_t st);
+
+int launch_probe_tr_read(const bf16_t* image, bf16_t* out, hipStream_t st);   // gemm_tn.hip debug probe
+int launch_pos_encoding(float* pe, int S, int channels, hipStream_t st);      // models/shared.py:36-48
+// generic small helpers
+int launch_swish_bwd_bf16(const bf16_t* pre, const bf16_t* dout, bf16_t* din, size_t n, hipStream_t st);

@@ -1,0 +1,242 @@
+"""absl-compatible command-line / flagfile parser (absl is not installed on the target image).
+
+Keeps the flag surface of the reference: the 41 flags of train_ncsn.py:48-128 and the 9 of
+sample_ncsn.py:51-66 with the same names, types and defaults, nested ``--flagfile=`` (later flags
+win, configs/ddpm-mel-32seq-512-large.cfg:1), ``--flag`` / ``--noflag`` / ``--flag=False`` booleans
+(configs/ddpm-base.cfg:8-10,14), comma lists (``--data_shape=32,512``), enums, ``None`` integers.
+Engine-only flags (``--dtype``, ``--synthetic``, ...) are added on top and do not collide.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence
+
+
+@dataclass
+class FlagDef:
+    name: str
+    kind: str            # int | float | bool | string | enum | list
+    default: Any
+    help: str = ""
+    choices: Optional[Sequence[str]] = None
+
+
+class FlagError(ValueError):
+    pass
+
+
+class FlagValues:
+    """Attribute access like absl's FLAGS; ``flags_into_string()`` like train_ncsn.py:557."""
+
+    def __init__(self, defs: Sequence[FlagDef]):
+        object.__setattr__(self, "_defs", {d.name: d for d in defs})
+        object.__setattr__(self, "_values", {d.name: d.default for d in defs})
+        object.__setattr__(self, "_present", set())
+        object.__setattr__(self, "_flagfile_dirs", [])
+
+    def __getattr__(self, name):
+        try:
+            return self._values[name]
+        except KeyError:
+            raise AttributeError(f"Unknown flag {name}") from None
+
+    def __setattr__(self, name, value):
+        if name not in self._defs:
+            raise AttributeError(f"Unknown flag {name}")
+        self._values[name] = value
+
+    def is_present(self, name: str) -> bool:
+        return name in self._present
+
+    def flag_values_dict(self) -> Dict[str, Any]:
+        return dict(self._values)
+
+    def flags_into_string(self) -> str:
+        out = []
+        for k, v in self._values.items():
+            d = self._defs[k]
+            if d.kind == "bool":
+                out.append(f"--{k}" if v else f"--no{k}")
+            elif d.kind == "list":
+                out.append(f"--{k}={','.join(str(x) for x in v)}")
+            elif v is not None:
+                out.append(f"--{k}={v}")
+        return "\n".join(out)
+
+    # ---- parsing
+    def _convert(self, d: FlagDef, text: str):
+        try:
+            if d.kind == "int":
+                return None if text in ("None", "") else int(text)
+            if d.kind == "float":
+                return float(text)
+            if d.kind == "bool":
+                t = text.strip().lower()
+                if t in ("true", "t", "1", "yes", "y"):
+                    return True
+                if t in ("false", "f", "0", "no", "n"):
+                    return False
+                raise ValueError(text)
+            if d.kind == "enum":
+                if text not in d.choices:
+                    raise FlagError(f"flag --{d.name}={text}: value should be one of <{'|'.join(d.choices)}>")
+                return text
+            if d.kind == "list":
+                return [t for t in text.split(",")] if text != "" else []
+            return text
+        except FlagError:
+            raise
+        except ValueError:
+            raise FlagError(f"flag --{d.name}={text}: invalid {d.kind} value") from None
+
+    def _set(self, name: str, value):
+        self._values[name] = value
+        self._present.add(name)
+
+    def read_flagfile(self, path: str, _depth: int = 0) -> List[str]:
+        if _depth > 16:
+            raise FlagError(f"flagfile nesting too deep at {path}")
+        if not os.path.exists(path):
+            # absl resolves nested flagfiles against the CWD (the reference is run from its repo
+            # root); additionally try the directories of the including flagfiles.
+            for base in reversed(self._flagfile_dirs):
+                for cand in (os.path.join(base, path), os.path.join(os.path.dirname(base), path)):
+                    if os.path.exists(cand):
+                        path = cand
+                        break
+                else:
+                    continue
+                break
+        if not os.path.exists(path):
+            raise FlagError(f"Can't open flagfile {path}")
+        self._flagfile_dirs.append(os.path.dirname(os.path.abspath(path)))
+        args: List[str] = []
+        with open(path) as f:
+            for line in f:
+                line = line.strip()
+                if not line or line.startswith("#") or line.startswith("//"):
+                    continue
+                args.append(line)
+        return args
+
+    def parse(self, argv: Sequence[str], _depth: int = 0) -> List[str]:
+        """Parses ``argv`` (without the program name); returns positional leftovers."""
+        rest: List[str] = []
+        i = 0
+        argv = list(argv)
+        while i < len(argv):
+            a = argv[i]
+            i += 1
+            if a == "--":
+                rest.extend(argv[i:])
+                break
+            if not a.startswith("-") or a == "-":
+                rest.append(a)
+                continue
+            body = a.lstrip("-")
+            name, eq, val = body.partition("=")
+            if name == "flagfile":
+                if not eq:
+                    if i >= len(argv):
+                        raise FlagError("--flagfile needs a path")
+                    val = argv[i]
+                    i += 1
+                rest.extend(self.parse(self.read_flagfile(val.strip(), _depth), _depth + 1))
+                continue
+            d = self._defs.get(name)
+            if d is None and name.startswith("no") and name[2:] in self._defs and \
+                    self._defs[name[2:]].kind == "bool":
+                if eq:
+                    raise FlagError(f"--{name} does not take a value")
+                self._set(name[2:], False)
+                continue
+            if d is None:
+                raise FlagError(f"Unknown command line flag '{name}'")
+            if d.kind == "bool":
+                self._set(name, self._convert(d, val) if eq else True)
+                continue
+            if not eq:
+                if i >= len(argv):
+                    raise FlagError(f"Missing value for flag --{name}")
+                val = argv[i]
+                i += 1
+            self._set(name, self._convert(d, val.strip()))
+        return rest
+
+
+def _D(name, kind, default, help="", choices=None):
+    return FlagDef(name, kind, default, help, choices)
+
+
+# train_ncsn.py:48-128 (same order)
+TRAIN_FLAGS: List[FlagDef] = [
+    _D("seed", "int", 0, "Random seed for network initialization."),
+    _D("loss", "enum", "dsm", "Loss function.", ("dsm", "ssm", "ddpm")),
+    _D("continuous_noise", "bool", True, "Continuous noise conditioning."),
+    _D("learning_rate", "float", 3e-4, "Learning rate for optimizer."),
+    _D("batch_size", "int", 128, "Batch size for training."),
+    _D("epochs", "int", 10, "Number of training epochs."),
+    _D("max_steps", "int", None, "Maximum number of training steps."),
+    _D("early_stopping", "bool", False, "Use early stopping to prevent overfitting."),
+    _D("grad_clip", "float", 1.0, "Max gradient norm for training."),
+    _D("lr_gamma", "float", 0.98, "Gamma for learning rate scheduler."),
+    _D("lr_schedule_interval", "int", 10000, "Number of steps between LR changes."),
+    _D("architecture", "string", "TransformerDDPM", "Class name of model architecture."),
+    _D("num_layers", "int", 6, "Number of encoder layers."),
+    _D("num_heads", "int", 8, "Number of attention heads."),
+    _D("num_mlp_layers", "int", 2, "Number of MLP layers."),
+    _D("mlp_dims", "int", 2048, "Number of channels per MLP layer."),
+    _D("sigma_begin", "float", 1.0, "Starting variance for noise schedule."),
+    _D("sigma_end", "float", 1e-2, "Ending variance for noise schedule."),
+    _D("schedule_type", "enum", "geometric", "Noise schedule configuration.", ("geometric", "linear", "fibonacci")),
+    _D("num_sigmas", "int", 15, "Number of sigma values (L) in noise schedule."),
+    _D("ld_steps", "int", 100, "Number of steps for annealed Langevin dynamics."),
+    _D("ld_epsilon", "float", 2e-6, "Step size for annealed Langevin dynamics."),
+    _D("sampling", "enum", "ald", "Sampling algorithm to use.", ("ald", "cas", "ddpm")),
+    _D("ema", "bool", True, "Exponential moving average smoothing."),
+    _D("mu", "float", 0.999, "Momentum parameter for EMA."),
+    _D("denoise", "bool", True, "Add additional denoising step during sampling (Song et al., 2020)."),
+    _D("data_shape", "list", ["2"], "Shape of data."),
+    _D("problem", "enum", "toy", "Problem to solve.", ("toy", "mnist", "vae")),
+    _D("dataset", "string", "./output/mix2d", "Path to directory containing data as train/eval tfrecord files."),
+    _D("pca_ckpt", "string", "", "PCA transform."),
+    _D("slice_ckpt", "string", "", "Slice transform."),
+    _D("dim_weights_ckpt", "string", "", "Dimension scale transform."),
+    _D("normalize", "bool", True, "Normalize dataset to [-1, 1]."),
+    _D("logging_freq", "int", 100, "Logging frequency."),
+    _D("snapshot_freq", "int", 5000, "Evaluation and checkpoint frequency."),
+    _D("snapshot_sampling", "bool", True, "Sample from score network during evaluation."),
+    _D("eval_samples", "int", 3000, "Number of samples to generate."),
+    _D("checkpoints_to_keep", "int", 50, "Number of checkpoints to keep."),
+    _D("save_ckpt", "bool", True, "Save model checkpoints at each evaluation step."),
+    _D("model_dir", "string", "./save/ncsn", "Directory to store model data."),
+    _D("verbose", "bool", True, "Toggle logging to stdout."),
+]
+
+# sample_ncsn.py:51-66
+SAMPLE_FLAGS: List[FlagDef] = [
+    _D("sample_seed", "int", 1, "Random number generator seed for sampling."),
+    _D("sampling_dir", "string", "samples", "Sampling directory."),
+    _D("sample_size", "int", 1000, "Number of samples."),
+    _D("compute_metrics", "bool", False, "Compute evaluation metrics for generated samples."),
+    _D("compute_final_only", "bool", False, "Do not include metrics for intermediate samples."),
+    _D("flush", "bool", True, "Flush generated samples to disk."),
+    _D("animate", "bool", False, "Generate animation of samples."),
+    _D("infill", "bool", False, "Infill."),
+    _D("interpolate", "bool", False, "Interpolate."),
+]
+
+# engine-only additions (no collision with the reference surface)
+ENGINE_FLAGS: List[FlagDef] = [
+    _D("dtype", "enum", "bf16", "GEMM operand precision of the HIP path.", ("bf16",)),
+    _D("synthetic", "bool", False, "Use synthetic latents clip(0.25*N(0,1),-1,1) instead of --dataset."),
+    _D("synthetic_examples", "int", 4096, "Synthetic examples per epoch."),
+    _D("sample_ema", "bool", False, "sample_ncsn: sample from the EMA weights (reference uses raw weights)."),
+    _D("graph", "bool", True, "Capture the sampling step in a hipGraph."),
+]
+
+
+def make_flags(include_sample: bool = False) -> FlagValues:
+    defs = list(TRAIN_FLAGS) + (list(SAMPLE_FLAGS) if include_sample else []) + list(ENGINE_FLAGS)
+    return FlagValues(defs)

@@ -1,0 +1,135 @@
+"""ctypes binding of the C-ABI in include/smd_hip.h.  Fails loudly: there is no CPU fallback.
+
+``get_lib()`` loads ``csrc/libsmd_hip.so`` (building it with hipcc first if it is missing or stale
+and hipcc exists).  Every wrapper raises ``ValueError`` for negative return codes (argument / state
+errors -- the reference raises Python asserts there, e.g. models/ncsn.py:32,40,50,154) and
+``RuntimeError`` for HIP errors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+from typing import List, Optional
+
+from . import build as _build
+
+_LIB: Optional[C.CDLL] = None
+
+c_f32p = C.POINTER(C.c_float)
+c_void = C.c_void_p
+c_i32 = C.c_int32
+c_u32 = C.c_uint32
+c_i64 = C.c_int64
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, c_i32) for n in ("arch", "data_channels", "seq_len", "num_layers", "num_heads",
+                                     "num_mlp_layers", "mlp_dims", "embed_channels", "film_channels",
+                                     "num_timesteps")]
+
+
+class TrainHyper(C.Structure):
+    _fields_ = [("lr0", C.c_float), ("lr_gamma", C.c_float), ("lr_interval", c_i32), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float), ("grad_clip", C.c_float), ("mu", C.c_float),
+                ("grad_scale", C.c_float)]
+
+
+class SampleIO(C.Structure):
+    _fields_ = [("x", c_void), ("t_ptr", c_void), ("z_in", c_void), ("seed_lo", c_u32), ("seed_hi", c_u32),
+                ("sample_offset", c_u32), ("infill_samples", c_void), ("infill_masks", c_void),
+                ("infill_z_in", c_void), ("metrics_partial", c_void), ("collection", c_void),
+                ("slot_table", c_void)]
+
+
+# name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
+_SIGS = {
+    "smd_last_error": (C.c_char_p, []),
+    "smd_abi_version": (C.c_int, []),
+    "smd_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(c_void)]),
+    "smd_engine_destroy": (None, [c_void]),
+    "smd_engine_num_tensors": (C.c_int, [c_void]),
+    "smd_engine_tensor_info": (C.c_int, [c_void, C.c_int, C.POINTER(C.c_char_p), C.POINTER(c_i64),
+                                         C.POINTER(c_i32), C.POINTER(c_i32)]),
+    "smd_engine_param_count": (c_i64, [c_void]),
+    "smd_engine_head_param_offset": (c_i64, [c_void]),
+    "smd_engine_wpack_elems": (c_i64, [c_void]),
+    "smd_engine_workspace_bytes": (c_i64, [c_void, C.c_int, C.c_int]),
+    "smd_engine_film_table_floats": (c_i64, [c_void]),
+    "smd_engine_padded_channels": (C.c_int, [c_void]),
+    "smd_engine_set_option": (C.c_int, [c_void, C.c_char_p, C.c_int]),
+    "smd_engine_bind_params": (C.c_int, [c_void, c_void, c_void]),
+    "smd_engine_bind_train": (C.c_int, [c_void] * 7),
+    "smd_engine_bind_workspace": (C.c_int, [c_void, c_void, c_i64, C.c_int, C.c_int, c_void]),
+    "smd_engine_bind_schedule": (C.c_int, [c_void] * 5),
+    "smd_engine_refresh_weights": (C.c_int, [c_void, c_void]),
+    "smd_engine_forward": (C.c_int, [c_void] * 5),
+    "smd_engine_loss_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_u32, c_u32, c_u32, C.c_float,
+                                           C.c_int, c_void]),
+    "smd_engine_loss_per_sample": (c_void, [c_void]),
+    "smd_engine_pred": (c_void, [c_void]),
+    "smd_engine_optimizer_step": (C.c_int, [c_void, C.POINTER(TrainHyper), c_void]),
+    "smd_engine_prepare_sampler": (C.c_int, [c_void, c_void]),
+    "smd_engine_init_state": (C.c_int, [c_void, c_void, c_u32, c_u32, c_u32, c_void]),
+    "smd_engine_load_state": (C.c_int, [c_void, c_void, c_void]),
+    "smd_engine_sample_step": (C.c_int, [c_void, C.POINTER(SampleIO), c_void]),
+    "smd_gemm_bf16_nt": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
+                                   c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
+    "smd_gemm_bf16_tn": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
+                                   c_void, c_i64, C.c_int, c_void]),
+    "smd_layernorm_fwd": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int,
+                                    C.c_int, c_void, c_void]),
+    "smd_layernorm_bwd": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int,
+                                    C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_void]),
+    "smd_attention_fwd": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "smd_attention_bwd": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
+    "smd_noise_embed": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
+    "smd_rng_normal": (C.c_int, [c_void, C.c_int, C.c_int, c_u32, c_u32, c_u32, c_u32, c_void]),
+    "smd_cast_pad_bf16": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
+    "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_u32,
+                                        c_u32, c_u32, c_void, c_void, c_void, c_void]),
+    "smd_probe_tr_read": (C.c_int, [c_void, c_void, c_void]),
+}
+
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "smd_hip.h")
+
+
+def declared_symbols() -> List[str]:
+    """Every function include/smd_hip.h declares (used by the no-GPU export test)."""
+    text = open(HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(smd_[a-z0-9_]+)\s*\(", text)))
+
+
+def get_lib() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB_PATH
+    if _build.is_stale():
+        try:
+            _build.build_library(verbose=False)
+        except Exception as e:  # no hipcc, or compile failure
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    f"libsmd_hip.so is missing and could not be built ({e}). The HIP extension is "
+                    "mandatory: there is no CPU fallback. Run `python -m smd_amd.build`.") from e
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError here = the .so is older than the header
+        fn.restype = res
+        fn.argtypes = args
+    if lib.smd_abi_version() != 1:
+        raise RuntimeError(f"libsmd_hip.so ABI {lib.smd_abi_version()} != 1; rebuild")
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc == 0:
+        return
+    msg = get_lib().smd_last_error()
+    text = f"{what}: {msg.decode() if msg else 'unknown error'} (rc={rc})"
+    if rc < 0:
+        raise ValueError(text)
+    raise RuntimeError(text)
