@@ -191,11 +191,17 @@ __global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
         }
       }
     }
+    // :381-383 sqrt(sum(v^2, axis=1) + 1e-10): axis 1 is the SEQUENCE axis for (B,S,C) states and the
+    // channel axis for the 2-D (B,C) states of DenseDDPM (S == 1 here).
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {                                // :381-383 (axis=1 is the sequence axis)
-      m_eps += sqrtf(acc_e[v] + 1e-10f);
-      m_step += sqrtf(acc_s[v] + 1e-10f);
-      m_z += sqrtf(acc_z[v] + 1e-10f);
+    for (int v = 0; v < VEC; ++v) {
+      if (a.S > 1) {
+        m_eps += sqrtf(acc_e[v] + 1e-10f);
+        m_step += sqrtf(acc_s[v] + 1e-10f);
+        m_z += sqrtf(acc_z[v] + 1e-10f);
+      } else {
+        m_eps += acc_e[v]; m_step += acc_s[v]; m_z += acc_z[v];
+      }
     }
   }
   if (a.metrics_partial) {
@@ -203,8 +209,11 @@ __global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[w][0] = m_eps; red[w][1] = m_step; red[w][2] = m_z; }
     __syncthreads();
-    if (threadIdx.x < 3)
-      a.metrics_partial[((size_t)t * a.B + b) * 3 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x];
+    if (threadIdx.x < 3) {
+      float v = red[0][threadIdx.x] + red[1][threadIdx.x];
+      if (a.S == 1) v = sqrtf(v + 1e-10f);
+      a.metrics_partial[((size_t)t * a.B + b) * 3 + threadIdx.x] = v;
+    }
   }
 }
 

@@ -451,13 +451,16 @@ int SmdEngine::backward_stem(hipStream_t st) {
 int SmdEngine::loss_backward(const float* x0, const int* labels, const float* eps_in, uint32_t seed_lo,
                              uint32_t seed_hi, uint32_t sample_offset, float inv_global_count, int stage,
                              hipStream_t st) {
-  SMD_ARG_CHECK(training_ && grads_ && alphas_prod_ext_, "loss_backward: bind a training workspace, the optimiser state and the schedule first");
-  SMD_ARG_CHECK(stage >= 0 && stage <= 2, "loss_backward: stage=%d", stage);
+  SMD_ARG_CHECK(training_ && alphas_prod_ext_, "loss_backward: bind a training workspace and the schedule first");
+  SMD_ARG_CHECK(stage >= 0 && stage <= 3, "loss_backward: stage=%d", stage);
+  SMD_ARG_CHECK(stage == 3 || grads_, "loss_backward: bind the optimiser state first");
   const int S = d_.seq_len, C = d_.data_channels;
-  if (stage == 0 || stage == 1) {
+  if (stage == 0 || stage == 1 || stage == 3) {     // 3 = loss only (eval_step, train_ncsn.py:206-221)
     SMD_ARG_CHECK(x0, "loss_backward: null batch");
-    hipError_t e = hipMemsetAsync(grads_, 0, sizeof(float) * (size_t)n_params_, st);
-    if (e != hipSuccess) { smd_set_error("loss_backward: memset: %s", hipGetErrorString(e)); return (int)e; }
+    if (stage != 3) {
+      hipError_t e = hipMemsetAsync(grads_, 0, sizeof(float) * (size_t)n_params_, st);
+      if (e != hipSuccess) { smd_set_error("loss_backward: memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
     QSampleArgs q;
     q.x0 = x0; q.B = batch_; q.S = S; q.C = C; q.Cp = Cp_; q.T = d_.num_timesteps;
     q.alphas_prod_ext = alphas_prod_ext_;
@@ -467,7 +470,7 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     RC(launch_q_sample(q, st));
     RC(run_network(nullptr, st));
     RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st));
-    RC(backward_head(st));
+    if (stage != 3) RC(backward_head(st));
   }
   if (stage == 0 || stage == 2) RC(backward_stem(st));
   return 0;

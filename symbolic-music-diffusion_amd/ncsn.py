@@ -1,0 +1,288 @@
+"""Host-side mirror of the reference's model / loss / sampler callables for the DDPM path.
+
+Same names, argument meaning and error behaviour as the reference seam:
+
+  create_model          train_ncsn.py:193-203        Model.__call__   models/ncsn.py:141-148
+  diffusion_loss        utils/losses.py:250-308      reduce_fn        utils/losses.py:22-30
+  diffusion_dynamics    utils/ebm_utils.py:280-405   collate_sampling_metrics  :408-428
+  sample                train_ncsn.py:499-551
+
+Every array computation runs in the HIP library (lib.py); this module only allocates tensors,
+sequences calls and reproduces the reference's output layouts and quirks.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import schedule as _sched
+from .engine import ARCH_IDS, Engine, NetConfig
+
+COLLECTION_STEPS = _sched.COLLECTION_STEPS
+
+
+# ------------------------------------------------------------------ rng keys
+@dataclass(frozen=True)
+class PRNGKey:
+    """Stand-in for jax.random.PRNGKey: a 64-bit seed for the engine's Philox streams.
+    (Bit-compatible threefry streams are a "next" row; parity tests pass draws explicitly.)"""
+    seed: int
+
+    def __post_init__(self):
+        object.__setattr__(self, "seed", int(self.seed) & 0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def split(key: PRNGKey, num: int = 2) -> Tuple[PRNGKey, ...]:
+    """jax.random.split look-alike (train_ncsn.py:318-319,358): ``num`` independent child keys."""
+    return tuple(PRNGKey(_splitmix64(key.seed ^ _splitmix64(i + 1))) for i in range(num))
+
+
+# ------------------------------------------------------------------ model
+class Model:
+    """nn.Model stand-in: ``model(x, cond) -> eps_hat`` on the HIP engine.
+
+    x: (B, *sample_shape) fp32, cond: (B, 1[, 1]) fp32 noise level sqrt(alpha_bar)
+    (models/ncsn.py:141-148 / 125-127)."""
+
+    def __init__(self, cfg: NetConfig, device: str = "cuda:0", seed: Optional[int] = 0,
+                 share_params_with: Optional["Model"] = None):
+        self.cfg = cfg
+        self.engine = Engine(cfg, device, share_params_with=share_params_with.engine if share_params_with else None)
+        if share_params_with is None and seed is not None:
+            self.engine.init_params(seed)
+        self._train_engine: Optional[Engine] = None
+
+    @property
+    def params(self) -> torch.Tensor:
+        return self.engine.params
+
+    def named_parameters(self):
+        return self.engine.named_views()
+
+    def __call__(self, x, cond):
+        x = torch.as_tensor(x)
+        cond = torch.as_tensor(cond)
+        assert x.shape[0] == cond.shape[0], (x.shape, cond.shape)           # models/ncsn.py:32,50
+        return self.engine.forward(x, cond)
+
+    def train_engine(self, ema: bool) -> Engine:
+        if self._train_engine is None:
+            self._train_engine = Engine(self.cfg, str(self.engine.device), share_params_with=self.engine)
+            self._train_engine.enable_training(ema)
+        return self._train_engine
+
+    def replace(self, params: torch.Tensor) -> "Model":
+        """nn.Model.replace(params=...) (train_ncsn.py:405-407): copies into this model's buffer."""
+        self.engine.params.copy_(params)
+        self.engine.refresh_weights()
+        return self
+
+    def num_parameters(self) -> int:
+        return self.engine.n_params
+
+
+def config_from_kwargs(architecture: str, input_shape: Sequence[int], model_kwargs: dict,
+                       num_timesteps: int = 1000) -> NetConfig:
+    if architecture not in ARCH_IDS:
+        raise ValueError(f"Unsupported architecture {architecture!r} (HIP engine: {sorted(ARCH_IDS)})")
+    input_shape = tuple(int(v) for v in input_shape)
+    if ARCH_IDS[architecture] == 1:
+        if len(input_shape) != 1:
+            raise ValueError(f"DenseDDPM takes (B, C) inputs, got per-example shape {input_shape}")
+        seq, ch = 1, input_shape[0]
+    else:
+        if len(input_shape) != 2:
+            raise ValueError(f"TransformerDDPM takes (B, S, C) inputs, got per-example shape {input_shape}")
+        seq, ch = input_shape
+    return NetConfig(architecture=architecture, data_channels=ch, seq_len=seq,
+                     num_layers=int(model_kwargs.get("num_layers", 6)),
+                     num_heads=int(model_kwargs.get("num_heads", 8)),
+                     num_mlp_layers=int(model_kwargs.get("num_mlp_layers", 2)),
+                     mlp_dims=int(model_kwargs.get("mlp_dims", 2048)), num_timesteps=num_timesteps)
+
+
+def create_model(rng: PRNGKey, input_shape, model_kwargs, batch_size=32, verbose=False, *,
+                 architecture: str = "TransformerDDPM", num_timesteps: int = 1000, device: str = "cuda:0") -> Model:
+    """train_ncsn.py:193-203.  ``architecture`` replaces the FLAGS.architecture global; DenseDDPM
+    accepts-and-ignores num_heads / num_mlp_layers like the reference's kwargs."""
+    del batch_size
+    cfg = config_from_kwargs(architecture, input_shape, model_kwargs, num_timesteps)
+    model = Model(cfg, device, seed=rng.seed & 0x7FFFFFFF)
+    if verbose:
+        from .train_utils import report_model
+        report_model(model)
+    return model
+
+
+# ------------------------------------------------------------------ objective
+def reduce_fn(x, mode):
+    """utils/losses.py:22-30."""
+    if mode == "none" or mode is None:
+        return x
+    if mode == "sum":
+        return x.sum()
+    if mode == "mean":
+        return x.mean()
+    raise ValueError("Unsupported reduction option.")
+
+
+def _ensure_schedule(engine: Engine, betas, with_sampler: bool) -> None:
+    betas = np.asarray(betas, dtype=np.float32)
+    need_film = with_sampler and (engine._sched_tensors is None or engine._sched_tensors["film"] is None)
+    if engine.betas is None or need_film or not np.array_equal(engine.betas, betas):
+        engine.set_schedule(betas, with_sampler=with_sampler)
+
+
+def diffusion_loss(batch, model: Model, betas, rng: PRNGKey, continuous_noise=False, reduction="mean", *,
+                   labels=None, eps=None):
+    """utils/losses.py:250-308 (forward only; the training step fuses it with the backward).
+    ``labels`` / ``eps`` pass the draws of :272-275 / :294 explicitly (parity mode); otherwise they
+    come from the engine's Philox streams keyed by ``rng``.  The continuous_noise flag has no effect
+    in the reference either: the discrete branch is commented out (:280-302)."""
+    del continuous_noise
+    eng = model.train_engine(ema=False)
+    batch = torch.as_tensor(batch).to(eng.device, torch.float32).contiguous()
+    _ensure_schedule(eng, betas, with_sampler=False)
+    eng.bind(batch.shape[0], training=True)
+    lab = None if labels is None else torch.as_tensor(labels).to(eng.device, torch.int32).contiguous()
+    e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
+    eng.loss_backward(batch, lab, e, seed=rng.seed, stage=3)
+    loss = eng.loss_per_sample().clone()
+    assert loss.shape == batch.shape[:1]                                          # utils/losses.py:306
+    return reduce_fn(loss, reduction)
+
+
+# ------------------------------------------------------------------ reverse sampler
+def collate_sampling_metrics(ld_metrics):
+    """utils/ebm_utils.py:408-428."""
+    num_metrics, num_sigmas, num_steps = ld_metrics.shape
+    del num_metrics
+    out = [[] for _ in range(num_sigmas)]
+    for i in range(num_sigmas):
+        grad_norm, step_norm, alpha, noise_norm = ld_metrics[:, i, :]
+        for j in range(num_steps):
+            out[i].append({"slope": grad_norm[j], "step": step_norm[j], "alpha": alpha[j], "noise": noise_norm[j]})
+    return out
+
+
+def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=None, denoise=None, infill=False,
+                       infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
+                       infill_noises: Optional[Callable] = None, t_start: Optional[int] = None, t_stop: int = 0,
+                       use_graph: bool = True, sample_offset: int = 0):
+    """utils/ebm_utils.py:280-405.  Returns (state, collection (41, ...), ld_metrics (4, T, 1)).
+
+    epsilon / T / denoise are null parameters as in the reference.  ``noises(t)`` /
+    ``infill_noises(t)`` supply the normal draws of :360-362 / :342-345 explicitly (parity mode);
+    otherwise the fused reverse-step kernel draws them from Philox keyed by (rng, global sample
+    index, t) and the step is replayed from a captured hipGraph.  ``t_start/t_stop`` bound the
+    walk (default T-1 .. 0)."""
+    del epsilon, T, denoise
+    eng = model.engine
+    dev = eng.device
+    init = torch.as_tensor(init).to(dev, torch.float32).contiguous()
+    B = init.shape[0]
+    if tuple(init.shape[1:]) != eng.cfg.sample_shape:
+        raise ValueError(f"init shape {tuple(init.shape)} != (B, {eng.cfg.sample_shape})")
+    nT = len(betas)
+    _ensure_schedule(eng, betas, with_sampler=True)
+    eng.bind(B, training=False)
+    eng.refresh_weights()          # the fp32 master may have been trained since the last call
+    eng.prepare_sampler()          # FiLM scale/shift tables for all T noise levels (3 small GEMMs per block)
+
+    if infill:
+        inf_s = torch.as_tensor(infill_samples).to(dev, torch.float32).contiguous()
+        inf_m = torch.as_tensor(infill_masks).to(dev, torch.float32).contiguous()
+        start = init * (1 - inf_m) + inf_s * inf_m                                # :321
+    else:
+        inf_s = inf_m = None
+        start = init
+    x = init.clone()
+    collection = torch.zeros((COLLECTION_STEPS + 1, *init.shape), dtype=torch.float32, device=dev)   # :322
+    collection[0] = start                                                          # :323
+    metrics_partial = torch.zeros((nT, B, 3), dtype=torch.float32, device=dev)
+    t_hi = nT - 1 if t_start is None else int(t_start)
+    t_ptr = torch.tensor([t_hi], dtype=torch.int32, device=dev)
+    eng.load_state(x)
+
+    io = _lib.SampleIO()
+    io.x = x.data_ptr(); io.t_ptr = t_ptr.data_ptr()
+    io.seed_lo = rng.seed & 0xFFFFFFFF; io.seed_hi = (rng.seed >> 32) & 0xFFFFFFFF
+    io.sample_offset = sample_offset
+    io.infill_samples = None if inf_s is None else inf_s.data_ptr()
+    io.infill_masks = None if inf_m is None else inf_m.data_ptr()
+    io.metrics_partial = metrics_partial.data_ptr()
+    io.collection = collection.data_ptr()
+    io.slot_table = eng.slot_table.data_ptr()
+    steps = list(range(t_hi, t_stop - 1, -1))
+    explicit = noises is not None or infill_noises is not None
+    if explicit:
+        zbuf = torch.zeros_like(x)
+        izbuf = torch.zeros_like(x) if infill else None
+        io.z_in = zbuf.data_ptr()
+        io.infill_z_in = None if izbuf is None else izbuf.data_ptr()
+        for t in steps:
+            if t > 0 and noises is not None:
+                zbuf.copy_(torch.as_tensor(noises(t)).to(dev, torch.float32))
+            if t > 0 and izbuf is not None and infill_noises is not None:
+                izbuf.copy_(torch.as_tensor(infill_noises(t)).to(dev, torch.float32))
+            eng.sample_step(io)
+    elif use_graph and len(steps) > 1:
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            eng.sample_step(io)                      # warm-up (also t = t_hi)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            eng.sample_step(io)
+        for _ in steps[1:]:
+            graph.replay()
+    else:
+        for _ in steps:
+            eng.sample_step(io)
+
+    # ld_metrics rows (grad_norm, step_norm, alpha_prod, noise_norm), one column per iteration (:380-405)
+    denom = float(B) if eng.S == 1 else float(B * eng.C)
+    per_t = metrics_partial.sum(dim=1) / denom                                      # (T, 3) indexed by t
+    ap = eng._sched_tensors["coef"][:, 5]
+    ld = torch.zeros((4, nT, 1), dtype=torch.float32, device=dev)
+    idx = torch.tensor(steps, device=dev, dtype=torch.long)
+    rows = torch.tensor([nT - 1 - t for t in steps], device=dev, dtype=torch.long)
+    ld[0, rows, 0] = per_t[idx, 0]
+    ld[1, rows, 0] = per_t[idx, 1]
+    ld[2, rows, 0] = ap[idx]
+    ld[3, rows, 0] = per_t[idx, 2]
+    return x, collection, ld
+
+
+def sample(scorenet: Model, sigmas, rng: PRNGKey, sample_shape, num_samples=2400, sampling="ald", epsilon=1e-3,
+           steps=100, denoise=True, *, sample_offset: int = 0, use_graph: bool = True):
+    """train_ncsn.py:499-551 for sampling == 'ddpm' (ald / cas need the NCSN nets that are broken
+    upstream; they are a "next" row)."""
+    if sampling != "ddpm":
+        if sampling in ("ald", "cas"):
+            raise NotImplementedError(f"sampling={sampling!r}: Langevin samplers are not on the DDPM hot path")
+        raise ValueError(f"Unknown sampling algorithm: {sampling}")
+    init_rng, ld_rng = split(rng)                                                    # :536
+    eng = scorenet.engine
+    if tuple(sample_shape) != eng.cfg.sample_shape:
+        raise ValueError(f"sample_shape {tuple(sample_shape)} != model shape {eng.cfg.sample_shape}")
+    eng.bind(num_samples, training=False)
+    init = torch.empty((num_samples, *sample_shape), dtype=torch.float32, device=eng.device)
+    eng.init_state(init, init_rng.seed, sample_offset)                               # :539-540 N(0,1)
+    generated, collection, ld_metrics = diffusion_dynamics(ld_rng, scorenet, sigmas, init, epsilon, steps, denoise,
+                                                           False, sample_offset=sample_offset, use_graph=use_graph)
+    return generated, collection, collate_sampling_metrics(ld_metrics.cpu().numpy())

@@ -1,0 +1,267 @@
+"""GPU parity tests of the single HIP kernels, called through the C-ABI (include/smd_hip.h).
+
+Each kernel is compared with a plain torch fp32/fp64 CPU computation of the same op on identical
+(bf16-rounded where applicable) inputs.  Tolerances are written next to each check.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import ddpm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import smd_amd.lib as lib
+    return lib.get_lib()
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def ck(lib_mod, rc):
+    import smd_amd.lib as lib
+    lib.check(rc)
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_probe_tr_read(L, dev):
+    """Documents the lane semantics of ds_read_b64_tr_b16 (what gemm_tn relies on)."""
+    img = bf(torch.arange(1024, dtype=torch.float32) % 256).to(dev)
+    out = torch.zeros(256, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_probe_tr_read(P(img), P(out), st()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(64, 4).long()
+    lane = torch.arange(64)
+    # expected (guide): lane l, elem j reads img[(l&15) + 16*j + 64*(l>>4)]
+    exp = torch.stack([(lane & 15) + 16 * j + 64 * (lane >> 4) for j in range(4)], dim=1)
+    print("tr_read lanes 0..3:", got[:4].tolist(), "lane 17:", got[17].tolist())
+    assert torch.equal(got, exp), f"unexpected ds_read_b64_tr_b16 layout:\n{got[:20]}"
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 42, 192), (1000, 4096, 512),
+                                   (8192, 2048, 2048), (64, 512, 2048)])
+def test_gemm_nt_plain(L, dev, M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = bf(torch.randn(M, K, generator=g))
+    Bt = bf(torch.randn(N, K, generator=g) * 0.5)
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ Bt.double().t() + bias.double()
+    Ad, Bd, bd = A.to(dev), Bt.to(dev), bias.to(dev)
+    out = torch.full((M, N), float("nan"), device=dev)
+    outb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), 0, None, 0, P(out), N, P(outb), N, st()))
+    torch.cuda.synchronize()
+    e = rel(out, ref)
+    eb = rel(outb.float(), ref)
+    print(f"gemm_nt {M}x{N}x{K}: rel fp32 {e:.2e} bf16 {eb:.2e}")
+    assert e < 2e-5            # fp32 accumulation of exact bf16 products
+    assert eb < 4e-3           # one bf16 rounding of the output
+
+
+def test_gemm_nt_epilogues(L, dev):
+    M, N, K = 320, 200, 128
+    g = torch.Generator().manual_seed(5)
+    A, Bt = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.2)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    z = A.double() @ Bt.double().t() + bias.double()
+    for act, fn in ((1, lambda v: O.gelu(v)), (2, lambda v: O.swish(v))):
+        ref = fn(z) + res.double()
+        out = torch.empty(M, N, device=dev)
+        ck(L, L.smd_gemm_bf16_nt(P(A.to(dev)), K, P(Bt.to(dev)), K, M, N, K, P(bias.to(dev)), act, P(res.to(dev)), N,
+                                 P(out), N, None, 0, st()))
+        torch.cuda.synchronize()
+        e = rel(out, ref)
+        print(f"gemm_nt epilogue act={act}: rel {e:.2e}")
+        assert e < 1e-4        # fast-math exp in gelu/swish
+    # in-place residual stream: out == residual buffer
+    buf = res.clone().to(dev)
+    ck(L, L.smd_gemm_bf16_nt(P(A.to(dev)), K, P(Bt.to(dev)), K, M, N, K, P(bias.to(dev)), 0, P(buf), N, P(buf), N,
+                             None, 0, st()))
+    torch.cuda.synchronize()
+    assert rel(buf, z + res.double()) < 2e-5
+
+
+def test_gemm_nt_rejects_bad_k(L, dev):
+    import smd_amd.lib as lib
+    a = torch.zeros(64, 96, dtype=torch.bfloat16, device=dev)
+    o = torch.zeros(64, 64, device=dev)
+    with pytest.raises(ValueError):
+        lib.check(L.smd_gemm_bf16_nt(P(a), 96, P(a), 96, 64, 64, 96, None, 0, None, 0, P(o), 64, None, 0, st()))
+
+
+@pytest.mark.parametrize("tr_path", [1, 0])
+@pytest.mark.parametrize("M,Kd,N,ldx", [(256, 128, 128, 128), (8192, 42, 128, 64), (96, 512, 4096, 512),
+                                         (8192, 128, 2048, 128), (8192, 2048, 2048, 2048), (4096, 2048, 146, 2048)])
+def test_gemm_tn(L, dev, tr_path, M, Kd, N, ldx):
+    g = torch.Generator().manual_seed(M + Kd + N)
+    ldy = (N + 63) // 64 * 64
+    X = torch.zeros(M, ldx)
+    X[:, :Kd] = torch.randn(M, Kd, generator=g)
+    Y = torch.zeros(M, ldy)
+    Y[:, :N] = torch.randn(M, N, generator=g) * 0.1
+    X, Y = bf(X), bf(Y)
+    ref = X[:, :Kd].double().t() @ Y[:, :N].double()
+    out = torch.full((Kd, N), float("nan"), device=dev)
+    Mp = (M + 63) // 64 * 64
+    scratch = torch.zeros(max(128, (Kd + N) * Mp if not tr_path else 128), dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_gemm_bf16_tn(P(X.to(dev)), ldx, P(Y.to(dev)), ldy, M, Kd, N, P(out), N, P(scratch), scratch.numel(),
+                             tr_path, st()))
+    torch.cuda.synchronize()
+    e = rel(out, ref)
+    print(f"gemm_tn tr={tr_path} M={M} Kd={Kd} N={N}: rel {e:.2e}")
+    assert e < 3e-5            # fp32 accumulation (split-K atomics reorder the sum)
+
+
+@pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),
+                                          (512, True, True), (1024, True, False)])
+def test_layernorm_fwd_bwd(L, dev, D, film, swish):
+    rows, rps = 128, 32
+    g = torch.Generator().manual_seed(D + 3 * film)
+    x = torch.randn(rows, D, generator=g) * 1.7 + 0.3
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    ns = rows // rps
+    ss = torch.cat([1 + 0.3 * torch.randn(ns, D, generator=g), 0.2 * torch.randn(ns, D, generator=g)], dim=1)
+    dout = bf(torch.randn(rows, D, generator=g))
+
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ssr = ss.double().requires_grad_(True)
+    y = O.layer_norm(xr, {"n.scale": gr, "n.bias": br}, "n")
+    if film:
+        sc = ssr[:, :D].repeat_interleave(rps, 0)
+        sh = ssr[:, D:].repeat_interleave(rps, 0)
+        y = sc * y + sh
+    if swish:
+        y = O.swish(y)
+    y.backward(dout.double())
+
+    xd, gd, bd, ssd = x.to(dev), gamma.to(dev), beta.to(dev), ss.contiguous().to(dev)
+    out = torch.zeros(rows, D, dtype=torch.bfloat16, device=dev)
+    fs = ssd if film else None
+    fsh = ssd[:, D:] if film else None
+    ck(L, L.smd_layernorm_fwd(P(xd), rows, D, P(gd), P(bd), P(fs), P(fsh), 2 * D, rps, int(swish), P(out), st()))
+    dx = torch.zeros(rows, D, device=dev)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    dss = torch.zeros(ns, 2 * D, device=dev)
+    partial = torch.zeros(rows * 2 * D, device=dev)
+    ck(L, L.smd_layernorm_bwd(P(xd), rows, D, P(gd), P(bd), P(fs), P(fsh), 2 * D, rps, int(swish), P(dout.to(dev)),
+                              P(dx), P(dg), P(db), P(dss) if film else None, P(dss[:, D:]) if film else None,
+                              P(partial), partial.numel(), st()))
+    torch.cuda.synchronize()
+    e_f = rel(out.float(), y)
+    print(f"ln D={D} film={film} swish={swish}: fwd {e_f:.2e} dx {rel(dx, xr.grad):.2e} "
+          f"dg {rel(dg, gr.grad):.2e} db {rel(db, br.grad):.2e}")
+    assert e_f < 4e-3                       # bf16 output rounding
+    assert rel(dx, xr.grad) < 1e-4
+    assert rel(dg, gr.grad) < 1e-4
+    assert rel(db, br.grad) < 1e-4
+    if film:
+        assert rel(dss, ssr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("H", [8, 16, 4])
+def test_attention_fwd_bwd(L, dev, H):
+    B, S, E = 5, 32, 128
+    d = E // H
+    g = torch.Generator().manual_seed(H)
+    qkv = bf(torch.randn(B * S, 3 * E, generator=g) * 1.5)
+    dout = bf(torch.randn(B * S, E, generator=g))
+    qr = qkv.double().requires_grad_(True)
+    q, k, v = qr.view(B, S, 3 * E).split(E, dim=-1)
+    q = q.reshape(B, S, H, d) / math.sqrt(d)
+    k, v = k.reshape(B, S, H, d), v.reshape(B, S, H, d)
+    w = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q, k), dim=-1)
+    o = torch.einsum("bhqk,bkhd->bqhd", w, v).reshape(B * S, E)
+    o.backward(dout.double())
+    out = torch.zeros(B * S, E, dtype=torch.bfloat16, device=dev)
+    dq = torch.zeros(B * S, 3 * E, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_attention_fwd(P(qkv.to(dev)), P(out), B, S, E, H, st()))
+    ck(L, L.smd_attention_bwd(P(qkv.to(dev)), P(dout.to(dev)), P(dq), B, S, E, H, st()))
+    torch.cuda.synchronize()
+    print(f"attention H={H}: fwd {rel(out.float(), o):.2e} bwd {rel(dq.float(), qr.grad):.2e}")
+    assert rel(out.float(), o) < 4e-3       # bf16 output rounding
+    assert rel(dq.float(), qr.grad) < 4e-3
+
+
+def test_attention_rejects_other_seq_len(L, dev):
+    import smd_amd.lib as lib
+    t = torch.zeros(16 * 384, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ValueError):
+        lib.check(L.smd_attention_fwd(P(t), P(t), 1, 16, 128, 8, st()))
+
+
+def test_noise_embed_and_rng(L, dev):
+    s = torch.tensor([1.0, 0.9999995, 0.5, 0.08137959, 1e-3])
+    out = torch.zeros(5, 128, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_noise_embed(P(s.to(dev)), 5, 128, P(out), 128, st()))
+    ref = O.noise_encoding(s.float()[:, None], 128)      # fp32 like the reference
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs().max()
+    print("noise_embed max abs err", float(err))
+    assert err < 1.2e-2                                  # bf16 rounding (2^-8) + fp32 range reduction at 5000 rad
+    # Philox normals: device vs the NumPy restatement
+    Bn, per = 3, 64
+    z = torch.zeros(Bn, per, device=dev)
+    ck(L, L.smd_rng_normal(P(z), Bn, per, 1234, 77, 3, 10, st()))
+    torch.cuda.synchronize()
+    ctr = np.zeros((Bn, per // 4, 4), np.uint32)
+    ctr[..., 0] = np.arange(per // 4)[None, :]
+    ctr[..., 1] = (np.arange(Bn) + 10)[:, None]
+    ctr[..., 2] = 3
+    ref = O.philox_normal4(ctr, np.array([1234, 77], np.uint32)).reshape(Bn, per)
+    err = np.abs(z.cpu().numpy() - ref).max()
+    print("philox normal max abs err", err)
+    assert err < 5e-5
+
+
+@pytest.mark.parametrize("C", [512, 42])
+def test_reverse_step_kernel(L, dev, C):
+    import smd_amd.schedule as S
+    B, Sq, T = 3, 32, 1000
+    betas = S.create_noise_schedule(1e-6, 0.01, T, "linear")
+    coef = torch.from_numpy(S.reverse_coefficient_table(betas))
+    slot = torch.from_numpy(S.collection_slot_table(T))
+    g = torch.Generator().manual_seed(C)
+    for t in (999, 975, 1, 0):
+        x = torch.randn(B, Sq, C, generator=g)
+        eh = torch.randn(B, Sq, C, generator=g)
+        z = torch.randn(B, Sq, C, generator=g)
+        model = lambda s_, c_: eh.double()
+        state, coll, met = O.diffusion_dynamics(model, betas, x.double(), lambda tt: z.double(), t_start=t, t_stop=t)
+        xd = x.clone().to(dev)
+        tp = torch.tensor([t], dtype=torch.int32, device=dev)
+        mp = torch.zeros(T, B, 3, device=dev)
+        cl = torch.zeros(41, B, Sq, C, device=dev)
+        ck(L, L.smd_ddpm_reverse_step(P(xd), P(eh.to(dev)), B, Sq, C, P(coef.to(dev)), P(tp), P(z.to(dev)), 0, 0, 0,
+                                      P(mp), P(cl), P(slot.to(dev)), st()))
+        torch.cuda.synchronize()
+        assert rel(xd, state) < 1e-5
+        m = mp[t].sum(0).cpu().double() / (B * C)
+        row = T - 1 - t
+        assert abs(m[0] - met[0, row, 0]) / met[0, row, 0] < 1e-5
+        assert abs(m[1] - met[1, row, 0]) / met[1, row, 0] < 1e-4
+        assert abs(m[2] - met[3, row, 0]) / (met[3, row, 0] + 1e-12) < 1e-4
+        s = int(slot[t])
+        if s >= 0:
+            assert rel(cl[s], coll[s]) < 1e-5
+        else:
+            assert float(cl.abs().max()) == 0.0

@@ -1,0 +1,118 @@
+"""Per-kernel micro-benchmark through the C-ABI (HIP events on the launch stream).
+
+  python tools/kbench.py [--reps 30]
+
+Prints one line per kernel/shape: average launch time, algorithmic TFLOP/s or GB/s, fraction of the
+MI355X peak (2.5 PFLOP/s dense bf16, 8 TB/s HBM).  Shapes are the ones of ddpm-mel-32seq-512 at
+batch 256 (R = 8192 rows).
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import smd_amd.lib as lib  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--json", default="")
+    a = ap.parse_args()
+    L = lib.get_lib()
+    dev = "cuda:0"
+    st = torch.cuda.current_stream().cuda_stream
+    rows = []
+
+    def rec(name, shape, ms, flops=None, bytes_=None):
+        r = {"kernel": name, "shape": shape, "ms": round(ms, 5)}
+        if flops:
+            r["tflops"] = round(flops / ms / 1e9, 1)
+            r["frac_mfma"] = round(flops / ms / 1e9 / 2500.0, 4)
+        if bytes_:
+            r["gbps"] = round(bytes_ / ms / 1e6, 1)
+            r["frac_hbm"] = round(bytes_ / ms / 1e6 / 8000.0, 4)
+        rows.append(r)
+        print(json.dumps(r))
+
+    R = 8192
+    bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+    # ---- NT GEMMs (forward + dgrad shapes)
+    for (M, N, K) in [(R, 2048, 2048), (R, 2048, 128), (R, 128, 2048), (R, 384, 128), (R, 128, 128), (R, 128, 512),
+                      (R, 512, 2048), (256, 4096, 512), (1000, 4096, 512)]:
+        A, Bt = bf(M, K), bf(N, K)
+        bias = torch.zeros(N, device=dev)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        f = lambda: lib.check(L.smd_gemm_bf16_nt(A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), 0, None, 0,
+                                                 None, 0, out.data_ptr(), N, st))
+        rec("gemm_nt", [M, N, K], timeit(f, a.reps), flops=2.0 * M * N * K)
+    # ---- TN GEMMs (wgrad shapes), both paths
+    for tr in (1, 0):
+        for (M, Kd, N) in [(R, 2048, 2048), (R, 128, 2048), (R, 2048, 128), (R, 128, 384), (R, 128, 128), (256, 512, 4096)]:
+            X, Y = bf(M, Kd), bf(M, N)
+            out = torch.empty(Kd, N, device=dev)
+            scratch = torch.zeros(max(128, (Kd + N) * M if not tr else 128), dtype=torch.bfloat16, device=dev)
+            f = lambda: lib.check(L.smd_gemm_bf16_tn(X.data_ptr(), Kd, Y.data_ptr(), N, M, Kd, N, out.data_ptr(), N,
+                                                     scratch.data_ptr(), scratch.numel(), tr, st))
+            rec(f"gemm_tn(tr={tr})", [M, Kd, N], timeit(f, a.reps), flops=2.0 * M * Kd * N)
+    # ---- LayerNorm
+    for D, film in ((128, 0), (2048, 0), (2048, 1)):
+        x = torch.randn(R, D, device=dev)
+        g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+        ss = torch.randn(R // 32, 2 * D, device=dev)
+        out = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+        f = lambda: lib.check(L.smd_layernorm_fwd(x.data_ptr(), R, D, g.data_ptr(), b.data_ptr(),
+                                                  ss.data_ptr() if film else None, ss[:, D:].data_ptr() if film else None,
+                                                  2 * D, 32, film, out.data_ptr(), st))
+        rec(f"layernorm_fwd(film={film})", [R, D], timeit(f, a.reps), bytes_=R * D * 6.0)
+        dout = bf(R, D)
+        dx = torch.empty(R, D, device=dev)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        dss = torch.zeros(R // 32, 2 * D, device=dev)
+        part = torch.empty(R * 2 * D // 16, device=dev)
+        f = lambda: lib.check(L.smd_layernorm_bwd(x.data_ptr(), R, D, g.data_ptr(), b.data_ptr(),
+                                                  ss.data_ptr() if film else None, ss[:, D:].data_ptr() if film else None,
+                                                  2 * D, 32, film, dout.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                  dss.data_ptr() if film else None, dss[:, D:].data_ptr() if film else None,
+                                                  part.data_ptr(), part.numel(), st))
+        rec(f"layernorm_bwd(film={film})", [R, D], timeit(f, a.reps), bytes_=R * D * 10.0)
+    # ---- attention
+    for H in (8, 16):
+        qkv = bf(R, 384)
+        o = torch.empty(R, 128, dtype=torch.bfloat16, device=dev)
+        dq = torch.empty(R, 384, dtype=torch.bfloat16, device=dev)
+        f = lambda: lib.check(L.smd_attention_fwd(qkv.data_ptr(), o.data_ptr(), R // 32, 32, 128, H, st))
+        rec(f"attention_fwd(H={H})", [R // 32, 32, 128], timeit(f, a.reps), bytes_=R * 512 * 2.0)
+        f = lambda: lib.check(L.smd_attention_bwd(qkv.data_ptr(), o.data_ptr(), dq.data_ptr(), R // 32, 32, 128, H, st))
+        rec(f"attention_bwd(H={H})", [R // 32, 32, 128], timeit(f, a.reps), bytes_=R * 1280 * 2.0)
+    # ---- reverse step
+    import smd_amd.schedule as S
+    coef = torch.from_numpy(S.reverse_coefficient_table(S.create_noise_schedule(1e-6, 0.01, 1000, "linear"))).to(dev)
+    x, eh = torch.randn(256, 32, 512, device=dev), torch.randn(256, 32, 512, device=dev)
+    tp = torch.tensor([500], dtype=torch.int32, device=dev)
+    f = lambda: lib.check(L.smd_ddpm_reverse_step(x.data_ptr(), eh.data_ptr(), 256, 32, 512, coef.data_ptr(), tp.data_ptr(),
+                                                  None, 1, 2, 0, None, None, None, st))
+    rec("ddpm_reverse_step(philox)", [256, 32, 512], timeit(f, a.reps), bytes_=256 * 32 * 512 * 12.0)
+    if a.json:
+        os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
+        json.dump(rows, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
