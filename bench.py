@@ -53,7 +53,7 @@ def parse():
 def cpu_baseline(cfg_name: str, batch: int):
     """Oracle on the host cores: 1 train step + 2 reverse steps at the benchmark batch size."""
     import ddpm_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     kw = dict(data_channels=512) if cfg_name == "base" else dict(data_channels=512, num_layers=8, num_heads=16,
                                                                  num_mlp_layers=3)
@@ -61,23 +61,40 @@ def cpu_baseline(cfg_name: str, batch: int):
     p = O.init_params(ocfg, 0, torch.float32)
     betas = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
     g = torch.Generator().manual_seed(1234)
-    x0 = torch.clamp(0.25 * torch.randn(batch, 32, 512, generator=g), -1, 1)
-    labels = torch.randint(1, 1001, (batch,), generator=g).numpy()
-    eps = torch.randn(batch, 32, 512, generator=g)
+    model = O.make_model(p, ocfg)
+    # size the bounded sample: probe 16 sequences, aim at <= ~25 s for 1 train step (~3 fwd) + 2 reverse steps
+    xp = torch.randn(16, 32, 512, generator=g)
+    with torch.no_grad():
+        model(xp, torch.ones(16, 1, 1))
+        t0 = time.perf_counter()
+        model(xp, torch.ones(16, 1, 1))
+        per_seq = (time.perf_counter() - t0) / 16
+    est = per_seq * batch * 5
+    b = batch if est <= 25 else max(16, int(batch * 25 / est) // 16 * 16)
+    log(f"cpu_baseline: {per_seq * 1e3:.1f} ms/sequence-forward on {cores} threads -> sample batch {b}")
+    x0 = torch.clamp(0.25 * torch.randn(b, 32, 512, generator=g), -1, 1)
+    labels = torch.randint(1, 1001, (b,), generator=g).numpy()
+    eps = torch.randn(b, 32, 512, generator=g)
     st = O.AdamState()
     t0 = time.perf_counter()
     O.train_step(p, ocfg, st, x0, betas, labels, eps, 1e-3, 1.0)
     t_train = time.perf_counter() - t0
-    zs = {t: torch.randn(batch, 32, 512, generator=g) for t in (999, 998)}
-    model = O.make_model(p, ocfg)
+    zs = {t: torch.randn(b, 32, 512, generator=g) for t in (999, 998)}
     t0 = time.perf_counter()
     with torch.no_grad():
         O.diffusion_dynamics(model, betas, eps, lambda t: zs[t], t_stop=998)
     t_sample = (time.perf_counter() - t0) / 2
-    return {"value": 2.0 / (t_train + t_sample), "unit": "denoising-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"oracle/ddpm_oracle.py torch-CPU fp32: 1 train_step + 2 reverse steps at batch {batch} "
-                      f"({t_train:.2f} s/train-step, {t_sample:.2f} s/sample-step); not JAX/XLA",
-            "train_steps_per_sec": 1.0 / t_train, "sample_steps_per_sec": 1.0 / t_sample}
+    scale = b / batch       # a step on `batch` sequences costs batch/b times the measured one
+    return {"value": round(2.0 / (t_train + t_sample) * scale, 5), "unit": "denoising-steps/sec", "cores": cores,
+            "kind": "port",
+            "sample": f"oracle/ddpm_oracle.py torch-CPU fp32 ({cores} threads): 1 train_step + 2 reverse steps on "
+                      f"{b} of the {batch} sequences ({t_train:.2f} s/train-step, {t_sample:.2f} s/sample-step), "
+                      f"rate scaled by {b}/{batch}; a restatement of the reference, not JAX/XLA",
+            "train_steps_per_sec": round(scale / t_train, 5), "sample_steps_per_sec": round(scale / t_sample, 5)}
+
+
+def log(msg: str) -> None:
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -95,10 +112,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
-
-    cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.config, a.batch)
 
     import smd_amd.lib as lib
     import smd_amd.ncsn as N
@@ -150,6 +163,7 @@ def main():
             eng.sample_step(io)
 
     do_train, do_sample = a.mode in ("both", "train"), a.mode in ("both", "sample")
+    log(f"rank {rank}: model + buffers ready, warming up")
     for _ in range(max(a.warmup, 1)):
         if do_train:
             one_train()
@@ -175,6 +189,8 @@ def main():
         torch.cuda.synchronize()
 
     t_train = t_sample = 0.0
+    torch.cuda.synchronize()
+    log(f"rank {rank}: warm-up done, timing {a.steps} steps")
     barrier()
     t0 = time.perf_counter()
     if do_train:
@@ -220,6 +236,11 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_nt_128x128_kernel", "shape": [R, M, M], "achieved": round(tf, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
                 "avg_launch_ms": round(ms, 5), "traffic": None}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log(f"GPU: train {t_train / a.steps * 1e3:.3f} ms/step, sample {t_sample / a.steps * 1e3:.3f} ms/step; CPU baseline next")
+        cpu = cpu_baseline(a.config, a.batch)
 
     if rank == 0:
         n_eval = (a.steps if do_train else 0) + (a.steps if do_sample else 0)

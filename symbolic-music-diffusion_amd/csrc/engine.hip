@@ -171,7 +171,7 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     }
     t.ln_partial_elems = ln_bwd_partial_elems((int)R, M > E ? M : E) / (S >= 32 ? 32 : 1) + 2 * (size_t)M;
     t.ln_partial = c.take<float>(t.ln_partial_elems);
-    t.colsum_partial_elems = (size_t)64 * (2 * M > 3 * E ? 2 * M : 3 * E);
+    t.colsum_partial_elems = (size_t)128 * (2 * M > 3 * E ? 2 * M : 3 * E);
     t.colsum_partial = c.take<float>(t.colsum_partial_elems);
     t.norm_partial = c.take<float>(1024);
     const size_t Mp = (R + 63) / 64 * 64;

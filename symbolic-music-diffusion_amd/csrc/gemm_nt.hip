@@ -4,22 +4,26 @@
 // (reference models/ncsn.py:53-61,155,161,165-171,178; models/shared.py:65,69).
 //
 // gfx950 design (cdna_hip_programming.md section 5):
-//   * 128x128x64 workgroup tile, 4 waves (2x2), each wave a 64x64 sub-tile = 2x2 MFMA
-//     v_mfma_f32_32x32x16_bf16 tiles, fp32 accumulation in 64 accumulator registers.
+//   * BM x 128 x 64 workgroup tile, BM in {128, 64, 32} chosen per launch so that skinny outputs
+//     (N = 128 / 384, the transformer encoder) still put >= 256 workgroups on the 256 CUs;
+//     4 waves, v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 //   * operands go HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS
-//     buffers (2 x 32 KiB), the next K-tile's DMA stays in flight across the barrier behind a
-//     counted s_waitcnt vmcnt(8) + raw s_barrier.
+//     buffers, the next K-tile's DMA stays in flight across the barrier behind a counted
+//     s_waitcnt vmcnt(N) + raw s_barrier.
 //   * LDS rows are 128 B (64 bf16); 16-byte chunk c of row r is stored at chunk c ^ ((r>>1)&7)
 //     (swizzle applied on the per-lane *source* address, matching XOR on the ds_read_b128
 //     fragment reads) so the 16-lane ds_read_b128 groups hit 16 distinct 16-B bank slots.
+//   * epilogue: the fp32 accumulator tile is staged through the (now free) LDS so that every lane
+//     handles 4 consecutive columns of one row: 16-byte bias/residual loads and 16-/8-byte
+//     stores, 512 B contiguous per 32 lanes (the MFMA C layout alone gives 2-byte scattered
+//     stores, which made the K=128 GEMMs store-bound).
 //   * XCD-aware bijective workgroup remap so one XCD's L2 sees a contiguous band of M-tiles.
 #include "smd_kernels.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;      // A + B
+constexpr int BN = 128, BK = 64;
+constexpr int STAGE_LD = 132;   // floats per staged row (128 + 4 pad: 528 B, 16-B aligned)
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -28,47 +32,121 @@ __device__ __forceinline__ void glds16(const bf16_t* g, unsigned char* lds_wave_
   __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ float epilogue_value(float acc, int row, int col, const GemmEpilogue& ep) {
+template <int N_> __device__ __forceinline__ void wait_vmcnt();
+template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+
+__device__ __forceinline__ float epilogue_scalar(float acc, int row, int col, const GemmEpilogue& ep) {
   float v = ep.alpha * acc;
   if (ep.bias) v += ep.bias[col];
   if (ep.pre_bf16) ep.pre_bf16[(size_t)row * ep.ld_pre + col] = f2bf(v);
   if (ep.act == SMD_ACT_GELU) v = geluf_(v);
   else if (ep.act == SMD_ACT_SWISH) v = swishf_(v);
   if (ep.aux_mode != SMD_AUX_NONE) {
-    float z = bf2f(ep.aux[(size_t)row * ep.ld_aux + col]);
+    const float z = bf2f(ep.aux[(size_t)row * ep.ld_aux + col]);
     v *= (ep.aux_mode == SMD_AUX_GELU_GRAD) ? gelu_gradf_(z) : swish_gradf_(z);
   }
   if (ep.res_f32) {
-    int rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+    const int rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
     v += ep.res_f32[(size_t)rr * ep.ld_res + col];
   }
   if (ep.res_bf16) v += bf2f(ep.res_bf16[(size_t)row * ep.ld_resb + col]);
   return v;
 }
 
-// 32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-__device__ __forceinline__ void store_one(float a, int row, int col, int M, int N, const GemmEpilogue& ep) {
-  if (col < N && row < M) {
-    const float v = epilogue_value(a, row, col, ep);
-    if (ep.out_f32) {
-      float* o = ep.out_f32 + (size_t)row * ep.ld_out + col;
-      *o = ep.accumulate ? (*o + v) : v;
+// 4 consecutive columns of one row; `vec_ok`: every pointer/ld is 4-element aligned and col+3 < N
+__device__ __forceinline__ void epilogue_quad(const float4 a, int row, int col, int N, bool vec_ok,
+                                              const GemmEpilogue& ep) {
+  if (vec_ok) {
+    float v[4] = {ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w};
+    if (ep.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(ep.bias + col);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (ep.out_bf16) ep.out_bf16[(size_t)row * ep.ld_outb + col] = f2bf(v);
+    if (ep.pre_bf16) {
+      bf16x4_t p;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[i] = f2bf(v[i]);
+      *reinterpret_cast<bf16x4_t*>(ep.pre_bf16 + (size_t)row * ep.ld_pre + col) = p;
+    }
+    if (ep.act == SMD_ACT_GELU) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = geluf_(v[i]);
+    } else if (ep.act == SMD_ACT_SWISH) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = swishf_(v[i]);
+    }
+    if (ep.aux_mode != SMD_AUX_NONE) {
+      const bf16x4_t z = *reinterpret_cast<const bf16x4_t*>(ep.aux + (size_t)row * ep.ld_aux + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i] *= (ep.aux_mode == SMD_AUX_GELU_GRAD) ? gelu_gradf_(bf2f(z[i])) : swish_gradf_(bf2f(z[i]));
+    }
+    if (ep.res_f32) {
+      const int rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
+      const float4 r = *reinterpret_cast<const float4*>(ep.res_f32 + (size_t)rr * ep.ld_res + col);
+      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+    }
+    if (ep.res_bf16) {
+      const bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(ep.res_bf16 + (size_t)row * ep.ld_resb + col);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += bf2f(r[i]);
+    }
+    if (ep.out_f32) {
+      float4* o = reinterpret_cast<float4*>(ep.out_f32 + (size_t)row * ep.ld_out + col);
+      if (ep.accumulate) {
+        const float4 c = *o;
+        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+      }
+      *o = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    if (ep.out_bf16) {
+      bf16x4_t p;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p[i] = f2bf(v[i]);
+      *reinterpret_cast<bf16x4_t*>(ep.out_bf16 + (size_t)row * ep.ld_outb + col) = p;
+    }
+  } else {
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (col + i < N) {
+        const float v = epilogue_scalar(av[i], row, col + i, ep);
+        if (ep.out_f32) {
+          float* o = ep.out_f32 + (size_t)row * ep.ld_out + col + i;
+          *o = ep.accumulate ? (*o + v) : v;
+        }
+        if (ep.out_bf16) ep.out_bf16[(size_t)row * ep.ld_outb + col + i] = f2bf(v);
+      }
+    }
   }
 }
+
 template <int... Es> struct IntSeq {};
 typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
+// 32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 template <int... Es>
-__device__ __forceinline__ void store_tile(const f32x16_t& acc, int row0, int col, int M, int N,
-                                           const GemmEpilogue& ep, IntSeq<Es...>) {
-  (store_one(acc[Es], row0 + (Es & 3) + 8 * (Es >> 2), col, M, N, ep), ...);
+__device__ __forceinline__ void stage_tile(const f32x16_t& acc, float* stage, int row0, int col, IntSeq<Es...>) {
+  ((stage[(row0 + (Es & 3) + 8 * (Es >> 2)) * STAGE_LD + col] = acc[Es]), ...);
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_128x128_kernel(
-    const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ Bt, int ldb, int M, int N,
-    int K, int tiles_n, int nwg, GemmEpilogue ep) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+template <int BM>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda,
+                                                      const bf16_t* __restrict__ Bt, int ldb, int M, int N, int K,
+                                                      int tiles_n, int nwg, int vec_epilogue, GemmEpilogue ep) {
+  constexpr int WM = BM >= 64 ? 2 : 1;            // waves along M
+  constexpr int WN = 4 / WM;                      // waves along N
+  constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile
+  constexpr int MT = WTM / 32, NT = WTN / 32;     // MFMA tiles per wave
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_PIECES = BM / 32;               // 1-KiB DMA pieces per wave per K-tile
+  constexpr int SROWS = BM < 64 ? BM : 64;        // rows staged per epilogue pass
+  constexpr int STAGE_BYTES = SROWS * STAGE_LD * 4;
+  constexpr int SMEM_BYTES = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   // ---- XCD-aware bijective remap (block b runs on XCD b % 8; give each XCD a contiguous band)
   const int bid = blockIdx.x;
@@ -80,44 +158,49 @@ __global__ __launch_bounds__(256) void gemm_nt_128x128_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w / WN, wc = w % WN;
 
-  // ---- per-lane DMA source pointers: wave w, piece j covers LDS rows (w*4+j)*8 .. +8
-  const bf16_t* a_src[4];
+  // ---- per-lane DMA source pointers. A: wave w piece j covers LDS rows (w*A_PIECES+j)*8 .. +8,
+  //      B: rows (w*4+j)*8 .. +8 ; 8 lanes per 128-B row, source chunk = lane&7 ^ ((row>>1)&7)
+  const bf16_t* a_src[A_PIECES];
   const bf16_t* b_src[4];
+#pragma unroll
+  for (int j = 0; j < A_PIECES; ++j) {
+    const int row = (w * A_PIECES + j) * 8 + (lane >> 3);
+    const int gk = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    int ga = m0 + row; ga = ga < M ? ga : M - 1;
+    a_src[j] = A + (size_t)ga * lda + gk;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int row = (w * 4 + j) * 8 + (lane >> 3);
-    const int gk = ((lane & 7) ^ ((row >> 1) & 7)) * 8;       // source chunk for LDS chunk lane&7
-    int ga = m0 + row; ga = ga < M ? ga : M - 1;
+    const int gk = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
     int gb = n0 + row; gb = gb < N ? gb : N - 1;
-    a_src[j] = A + (size_t)ga * lda + gk;
     b_src[j] = Bt + (size_t)gb * ldb + gk;
   }
 
   auto issue_tile = [&](int kt, int buf) {
-    unsigned char* base = smem + buf * BUF_BYTES + w * 4096;
+    unsigned char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(a_src[j] + kt * BK, base + j * 1024);
+    for (int j = 0; j < A_PIECES; ++j) glds16(a_src[j] + kt * BK, base + (w * A_PIECES + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(b_src[j] + kt * BK, base + TILE_BYTES + j * 1024);
+    for (int j = 0; j < 4; ++j) glds16(b_src[j] + kt * BK, base + A_BYTES + (w * 4 + j) * 1024);
   };
 
-  // ---- fragment read offsets (bytes) within an operand tile
+  // ---- fragment read offsets (bytes) within a buffer
   const int fsw = (lane >> 1) & 7;        // == (row>>1)&7 for row = 32*k + (lane&31)
   const int kh = lane >> 5;               // which 8-wide k half of a 16-wide MFMA k-step
-  int a_off[2], b_off[2];
+  int a_off[MT], b_off[NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    a_off[i] = (wr * 64 + i * 32 + (lane & 31)) * 128;
-    b_off[i] = TILE_BYTES + (wc * 64 + i * 32 + (lane & 31)) * 128;
-  }
+  for (int i = 0; i < MT; ++i) a_off[i] = (wr * WTM + i * 32 + (lane & 31)) * 128;
+#pragma unroll
+  for (int i = 0; i < NT; ++i) b_off[i] = A_BYTES + (wc * WTN + i * 32 + (lane & 31)) * 128;
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
@@ -127,50 +210,71 @@ __global__ __launch_bounds__(256) void gemm_nt_128x128_kernel(
     const int buf = kt & 1;
     if (kt + 1 < nk) {
       issue_tile(kt + 1, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile kt landed, tile kt+1 in flight
+      wait_vmcnt<A_PIECES + 4>();        // tile kt landed, tile kt+1 stays in flight
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* tb = smem + buf * BUF_BYTES;
-    // fragment reads for k-step ks+1 are issued ahead of the MFMAs of k-step ks
-    bf16x8_t af[2][2], bfr[2][2];
-    {
-      const int coff = (kh ^ fsw) << 4;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        af[0][i] = *reinterpret_cast<const bf16x8_t*>(tb + a_off[i] + coff);
-        bfr[0][i] = *reinterpret_cast<const bf16x8_t*>(tb + b_off[i] + coff);
-      }
-    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < 3) {
-        const int coff = (((ks + 1) * 2 + kh) ^ fsw) << 4;
+      const int coff = ((ks * 2 + kh) ^ fsw) << 4;
+      bf16x8_t af[MT], bfr[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          af[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8_t*>(tb + a_off[i] + coff);
-          bfr[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8_t*>(tb + b_off[i] + coff);
-        }
-      }
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(tb + a_off[i] + coff);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NT; ++i) bfr[i] = *reinterpret_cast<const bf16x8_t*>(tb + b_off[i] + coff);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bfr[ks & 1][j],
-                                                              acc[i][j], 0, 0, 0);
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();                          // all waves done with buf before re-fill
+    __builtin_amdgcn_s_barrier();        // all waves done with buf before it is re-filled / re-used
   }
 
-  // ---- epilogue (store_tile is expanded with compile-time accumulator indices)
-  store_tile(acc[0][0], m0 + wr * 64 + 4 * kh, n0 + wc * 64 + (lane & 31), M, N, ep, Seq16{});
-  store_tile(acc[0][1], m0 + wr * 64 + 4 * kh, n0 + wc * 64 + 32 + (lane & 31), M, N, ep, Seq16{});
-  store_tile(acc[1][0], m0 + wr * 64 + 32 + 4 * kh, n0 + wc * 64 + (lane & 31), M, N, ep, Seq16{});
-  store_tile(acc[1][1], m0 + wr * 64 + 32 + 4 * kh, n0 + wc * 64 + 32 + (lane & 31), M, N, ep, Seq16{});
+  // ---- epilogue through LDS: SROWS rows per pass, every lane owns 4 consecutive columns
+  float* stage = reinterpret_cast<float*>(smem);
+  constexpr int PASSES = BM / SROWS;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    if (p > 0) __syncthreads();
+    // rows [p*SROWS, (p+1)*SROWS) of the block tile: wave rows wr*WTM .. +WTM
+    if (wr * WTM >= p * SROWS && wr * WTM < (p + 1) * SROWS) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          stage_tile(acc[i][j], stage, wr * WTM - p * SROWS + i * 32 + 4 * kh, wc * WTN + j * 32 + (lane & 31),
+                     Seq16{});
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const int col = n0 + c4;
+#pragma unroll
+    for (int i = 0; i < SROWS / 8; ++i) {
+      const int rs = (tid >> 5) + 8 * i;
+      const int row = m0 + p * SROWS + rs;
+      if (row < M && col < N) {
+        const float4 a4 = *reinterpret_cast<const float4*>(stage + rs * STAGE_LD + c4);
+        epilogue_quad(a4, row, col, N, vec_epilogue && (col + 3 < N), ep);
+      }
+    }
+  }
 }
+
+template <int BM>
+void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K, int vec, const GemmEpilogue& ep,
+               hipStream_t st) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  hipLaunchKernelGGL(gemm_nt_kernel<BM>, dim3(nwg), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, vec, ep);
+}
+
+inline bool al4(const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && ld % 4 == 0); }
+inline bool al4h(const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 7) == 0 && ld % 4 == 0); }
 
 }  // namespace
 
@@ -183,10 +287,17 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
                 "gemm_nt: lda=%d ldb=%d must be >=K and multiples of 8", lda, ldb);
   SMD_ARG_CHECK(ep.out_f32 || ep.out_bf16 || ep.pre_bf16, "gemm_nt: no output");
   SMD_ARG_CHECK(ep.aux_mode == SMD_AUX_NONE || ep.aux, "gemm_nt: aux_mode without aux");
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL(gemm_nt_128x128_kernel, dim3(nwg), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K,
-                     tiles_n, nwg, ep);
+  const int vec = (al4(ep.bias, 4) && al4(ep.res_f32, ep.ld_res) && al4(ep.out_f32, ep.ld_out) &&
+                   al4h(ep.pre_bf16, ep.ld_pre) && al4h(ep.aux, ep.ld_aux) && al4h(ep.res_bf16, ep.ld_resb) &&
+                   al4h(ep.out_bf16, ep.ld_outb)) ? 1 : 0;
+  // tile height: keep >= ~256 workgroups on the chip when the output is skinny
+  const int tiles_n = (N + BN - 1) / BN;
+  const long wg128 = (long)((M + 127) / 128) * tiles_n;
+  const long wg64 = (long)((M + 63) / 64) * tiles_n;
+  if (M <= 32) launch_bm<32>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (wg128 >= 512) launch_bm<128>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (wg64 >= 256 || M <= 64) launch_bm<64>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else launch_bm<32>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   SMD_LAUNCH_CHECK();
   return 0;
 }

@@ -209,17 +209,31 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const bf16_t* __rest
   int r_end = r_begin + rows_per_chunk;
   r_end = r_end < rows ? r_end : rows;
   if (c >= cols) return;
-  float s = 0.0f;
-  for (int r = r_begin; r < r_end; ++r) s += bf2f(dY[(size_t)r * ldy + c]);
-  partial[(size_t)blockIdx.y * cols + c] = s;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;      // 4 independent chains keep loads in flight
+  int r = r_begin;
+  for (; r + 3 < r_end; r += 4) {
+    s0 += bf2f(dY[(size_t)r * ldy + c]);
+    s1 += bf2f(dY[(size_t)(r + 1) * ldy + c]);
+    s2 += bf2f(dY[(size_t)(r + 2) * ldy + c]);
+    s3 += bf2f(dY[(size_t)(r + 3) * ldy + c]);
+  }
+  for (; r < r_end; ++r) s0 += bf2f(dY[(size_t)r * ldy + c]);
+  partial[(size_t)blockIdx.y * cols + c] = (s0 + s1) + (s2 + s3);
 }
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ partial, int nchunks,
                                                             int cols, float* __restrict__ out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= cols) return;
-  float s = 0.0f;
-  for (int k = 0; k < nchunks; ++k) s += partial[(size_t)k * cols + c];
-  out[c] = s;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int k = 0;
+  for (; k + 3 < nchunks; k += 4) {
+    s0 += partial[(size_t)k * cols + c];
+    s1 += partial[(size_t)(k + 1) * cols + c];
+    s2 += partial[(size_t)(k + 2) * cols + c];
+    s3 += partial[(size_t)(k + 3) * cols + c];
+  }
+  for (; k < nchunks; ++k) s0 += partial[(size_t)k * cols + c];
+  out[c] = (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace
@@ -237,8 +251,8 @@ int launch_transpose_bf16(const bf16_t* in, int ld_in, int rows, int cols, bf16_
 int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out, float* partial,
                        size_t partial_elems, hipStream_t st) {
   SMD_ARG_CHECK(dY && out && partial && rows > 0 && cols > 0, "colsum_bf16: bad arguments");
-  int nchunks = (rows + 255) / 256;
-  if (nchunks > 64) nchunks = 64;
+  int nchunks = (rows + 63) / 64;
+  if (nchunks > 128) nchunks = 128;
   const int rows_per_chunk = (rows + nchunks - 1) / nchunks;
   nchunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
   SMD_ARG_CHECK(partial_elems >= (size_t)nchunks * cols, "colsum_bf16: workspace too small");

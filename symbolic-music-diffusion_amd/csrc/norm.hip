@@ -235,15 +235,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdDev a) {
 }
 
 // dgamma[c] += sum_g partial[g][0][c] ; dbeta likewise (fixed order -> deterministic)
+// 64 columns x 4 group-slices per block: many independent loads in flight instead of one long
+// dependent chain per column (the one-thread-per-column version was latency-bound at ~65 us).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int ngroups, int D,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * D) return;
-  const int which = c / D, cc = c - which * D;
-  float s = 0.f;
-  for (int gidx = 0; gidx < ngroups; ++gidx) s += partial[((size_t)gidx * 2 + which) * D + cc];
-  float* dst = which ? dbeta : dgamma;
-  dst[cc] += s;
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);      // column in [0, 2D)
+  const int slice = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    const int which = c / D, cc = c - which * D;
+    const float* base = partial + (size_t)which * D + cc;
+    int gidx = slice;
+    for (; gidx + 12 < ngroups; gidx += 16) {
+      s0 += base[(size_t)gidx * 2 * D];
+      s1 += base[(size_t)(gidx + 4) * 2 * D];
+      s2 += base[(size_t)(gidx + 8) * 2 * D];
+      s3 += base[(size_t)(gidx + 12) * 2 * D];
+    }
+    for (; gidx < ngroups; gidx += 4) s0 += base[(size_t)gidx * 2 * D];
+  }
+  red[slice][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && c < 2 * D) {
+    const int which = c / D, cc = c - which * D;
+    float* dst = which ? dbeta : dgamma;
+    const int l = threadIdx.x;
+    dst[cc] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
 }
 
 int ln_group_rows(const LnArgs& f) { return f.film_scale ? f.rows_per_sample : 32; }
@@ -315,7 +334,7 @@ int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
   d.group_rows = gr;
   SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st));
   SMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.f.D + 255) / 256), dim3(256), 0, st, a.partial, ngroups,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.f.D + 63) / 64), dim3(256), 0, st, a.partial, ngroups,
                      a.f.D, a.dgamma, a.dbeta);
   SMD_LAUNCH_CHECK();
   return 0;

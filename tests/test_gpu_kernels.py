@@ -83,10 +83,11 @@ def test_gemm_nt_epilogues(L, dev):
     A, Bt = bf(torch.randn(M, K, generator=g)), bf(torch.randn(N, K, generator=g) * 0.2)
     bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     z = A.double() @ Bt.double().t() + bias.double()
+    Ad, Bd, bd, rd = A.to(dev), Bt.to(dev), bias.to(dev), res.to(dev)     # keep alive until the sync
     for act, fn in ((1, lambda v: O.gelu(v)), (2, lambda v: O.swish(v))):
         ref = fn(z) + res.double()
         out = torch.empty(M, N, device=dev)
-        ck(L, L.smd_gemm_bf16_nt(P(A.to(dev)), K, P(Bt.to(dev)), K, M, N, K, P(bias.to(dev)), act, P(res.to(dev)), N,
+        ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), act, P(rd), N,
                                  P(out), N, None, 0, st()))
         torch.cuda.synchronize()
         e = rel(out, ref)
@@ -94,7 +95,7 @@ def test_gemm_nt_epilogues(L, dev):
         assert e < 1e-4        # fast-math exp in gelu/swish
     # in-place residual stream: out == residual buffer
     buf = res.clone().to(dev)
-    ck(L, L.smd_gemm_bf16_nt(P(A.to(dev)), K, P(Bt.to(dev)), K, M, N, K, P(bias.to(dev)), 0, P(buf), N, P(buf), N,
+    ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), 0, P(buf), N, P(buf), N,
                              None, 0, st()))
     torch.cuda.synchronize()
     assert rel(buf, z + res.double()) < 2e-5
@@ -123,7 +124,8 @@ def test_gemm_tn(L, dev, tr_path, M, Kd, N, ldx):
     out = torch.full((Kd, N), float("nan"), device=dev)
     Mp = (M + 63) // 64 * 64
     scratch = torch.zeros(max(128, (Kd + N) * Mp if not tr_path else 128), dtype=torch.bfloat16, device=dev)
-    ck(L, L.smd_gemm_bf16_tn(P(X.to(dev)), ldx, P(Y.to(dev)), ldy, M, Kd, N, P(out), N, P(scratch), scratch.numel(),
+    Xd, Yd = X.to(dev), Y.to(dev)
+    ck(L, L.smd_gemm_bf16_tn(P(Xd), ldx, P(Yd), ldy, M, Kd, N, P(out), N, P(scratch), scratch.numel(),
                              tr_path, st()))
     torch.cuda.synchronize()
     e = rel(out, ref)
@@ -163,7 +165,8 @@ def test_layernorm_fwd_bwd(L, dev, D, film, swish):
     dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
     dss = torch.zeros(ns, 2 * D, device=dev)
     partial = torch.zeros(rows * 2 * D, device=dev)
-    ck(L, L.smd_layernorm_bwd(P(xd), rows, D, P(gd), P(bd), P(fs), P(fsh), 2 * D, rps, int(swish), P(dout.to(dev)),
+    doutd = dout.to(dev)
+    ck(L, L.smd_layernorm_bwd(P(xd), rows, D, P(gd), P(bd), P(fs), P(fsh), 2 * D, rps, int(swish), P(doutd),
                               P(dx), P(dg), P(db), P(dss) if film else None, P(dss[:, D:]) if film else None,
                               P(partial), partial.numel(), st()))
     torch.cuda.synchronize()
@@ -194,8 +197,9 @@ def test_attention_fwd_bwd(L, dev, H):
     o.backward(dout.double())
     out = torch.zeros(B * S, E, dtype=torch.bfloat16, device=dev)
     dq = torch.zeros(B * S, 3 * E, dtype=torch.bfloat16, device=dev)
-    ck(L, L.smd_attention_fwd(P(qkv.to(dev)), P(out), B, S, E, H, st()))
-    ck(L, L.smd_attention_bwd(P(qkv.to(dev)), P(dout.to(dev)), P(dq), B, S, E, H, st()))
+    qd, dd = qkv.to(dev), dout.to(dev)
+    ck(L, L.smd_attention_fwd(P(qd), P(out), B, S, E, H, st()))
+    ck(L, L.smd_attention_bwd(P(qd), P(dd), P(dq), B, S, E, H, st()))
     torch.cuda.synchronize()
     print(f"attention H={H}: fwd {rel(out.float(), o):.2e} bwd {rel(dq.float(), qr.grad):.2e}")
     assert rel(out.float(), o) < 4e-3       # bf16 output rounding
@@ -212,7 +216,8 @@ def test_attention_rejects_other_seq_len(L, dev):
 def test_noise_embed_and_rng(L, dev):
     s = torch.tensor([1.0, 0.9999995, 0.5, 0.08137959, 1e-3])
     out = torch.zeros(5, 128, dtype=torch.bfloat16, device=dev)
-    ck(L, L.smd_noise_embed(P(s.to(dev)), 5, 128, P(out), 128, st()))
+    sd = s.to(dev)
+    ck(L, L.smd_noise_embed(P(sd), 5, 128, P(out), 128, st()))
     ref = O.noise_encoding(s.float()[:, None], 128)      # fp32 like the reference
     torch.cuda.synchronize()
     err = (out.float().cpu() - ref).abs().max()
@@ -240,6 +245,7 @@ def test_reverse_step_kernel(L, dev, C):
     betas = S.create_noise_schedule(1e-6, 0.01, T, "linear")
     coef = torch.from_numpy(S.reverse_coefficient_table(betas))
     slot = torch.from_numpy(S.collection_slot_table(T))
+    coefd, slotd = coef.to(dev), slot.to(dev)
     g = torch.Generator().manual_seed(C)
     for t in (999, 975, 1, 0):
         x = torch.randn(B, Sq, C, generator=g)
@@ -251,8 +257,9 @@ def test_reverse_step_kernel(L, dev, C):
         tp = torch.tensor([t], dtype=torch.int32, device=dev)
         mp = torch.zeros(T, B, 3, device=dev)
         cl = torch.zeros(41, B, Sq, C, device=dev)
-        ck(L, L.smd_ddpm_reverse_step(P(xd), P(eh.to(dev)), B, Sq, C, P(coef.to(dev)), P(tp), P(z.to(dev)), 0, 0, 0,
-                                      P(mp), P(cl), P(slot.to(dev)), st()))
+        ehd, zd = eh.to(dev), z.to(dev)
+        ck(L, L.smd_ddpm_reverse_step(P(xd), P(ehd), B, Sq, C, P(coefd), P(tp), P(zd), 0, 0, 0,
+                                      P(mp), P(cl), P(slotd), st()))
         torch.cuda.synchronize()
         assert rel(xd, state) < 1e-5
         m = mp[t].sum(0).cpu().double() / (B * C)
