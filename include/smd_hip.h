@@ -124,10 +124,13 @@ enum { SMD_EPI_NONE = 0, SMD_EPI_GELU = 1, SMD_EPI_SWISH = 2 };
 int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, int M, int N, int K,
                      const float* bias, int act, const float* residual, int ld_res, float* out_f32, int ld_out,
                      smd_bf16* out_bf16, int ld_outb, void* stream);
-/* dW[Kd,N] = X[M,Kd]^T dY[M,N] (weight gradient); zero_page: >= 128 zeroed bf16 (tr_path=1) or a
- * scratch of (Kd+N)*roundup(M,64) bf16 (tr_path=0) */
+/* dW[Kd,N] = X[M,Kd]^T dY[M,N] and db[N] = colsum(dY) (weight + bias gradient of nn.Dense).
+ * tr_path 1: zero_page = 128 zeroed bf16, slab = smd_gemm_tn_slab_elems() floats (split-K partials);
+ * tr_path 0: scratch = (Kd+N)*roundup(M,64) bf16 for explicit transposes (+ slab for the bias). */
 int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out,
-                     int ldo, smd_bf16* scratch, int64_t scratch_elems, int tr_path, void* stream);
+                     int ldo, float* bias_out, const smd_bf16* zero_page, float* slab, int64_t slab_elems,
+                     smd_bf16* scratch, int64_t scratch_elems, int tr_path, void* stream);
+int64_t smd_gemm_tn_slab_elems(void);
 /* flax.nn.LayerNorm (+ FiLM + swish), models/shared.py:62-68 */
 int smd_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
                       const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample,

@@ -149,9 +149,15 @@ int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, in
   return launch_gemm_nt(B(A), lda, B(Bt), ldb, M, N, K, ep, S(stream));
 }
 int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out, int ldo,
-                     smd_bf16* scratch, int64_t scratch_elems, int tr_path, void* stream) {
-  return launch_gemm_tn(B(X), ldx, B(dY), ldy, M, Kd, N, out, ldo, B(scratch), (size_t)scratch_elems, tr_path, S(stream));
+                     float* bias_out, const smd_bf16* zero_page, float* slab, int64_t slab_elems, smd_bf16* scratch,
+                     int64_t scratch_elems, int tr_path, void* stream) {
+  TnLaunch t;
+  t.X = B(X); t.ldx = ldx; t.dY = B(dY); t.ldy = ldy; t.Mrows = M; t.Kd = Kd; t.N = N; t.out = out; t.ldo = ldo;
+  t.bias_out = bias_out; t.zero_page = B(zero_page); t.slab = slab; t.slab_elems = (size_t)slab_elems;
+  t.scratch = B(scratch); t.scratch_elems = (size_t)scratch_elems; t.tr_path = tr_path;
+  return launch_gemm_tn(t, S(stream));
 }
+int64_t smd_gemm_tn_slab_elems(void) { return (int64_t)gemm_tn_slab_elems(); }
 int smd_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta, const float* film_scale,
                       const float* film_shift, int ld_film, int rows_per_sample, int swish, smd_bf16* out, void* stream) {
   LnArgs a;

@@ -171,8 +171,8 @@ class SmdEngine {
     bf16_t* df1 = nullptr;                // [B][4F]
     float* ln_partial = nullptr;
     size_t ln_partial_elems = 0;
-    float* colsum_partial = nullptr;
-    size_t colsum_partial_elems = 0;
+    float* tn_slab = nullptr;             // split-K partial tiles of the wgrad kernel
+    size_t tn_slab_elems = 0;
     float* norm_partial = nullptr;        // [1024]
     bf16_t* zero_page = nullptr;          // [128]
     bf16_t* tn_scratch = nullptr;         // fallback wgrad transposes

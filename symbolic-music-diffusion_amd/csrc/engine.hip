@@ -171,8 +171,8 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     }
     t.ln_partial_elems = ln_bwd_partial_elems((int)R, M > E ? M : E) / (S >= 32 ? 32 : 1) + 2 * (size_t)M;
     t.ln_partial = c.take<float>(t.ln_partial_elems);
-    t.colsum_partial_elems = (size_t)128 * (2 * M > 3 * E ? 2 * M : 3 * E);
-    t.colsum_partial = c.take<float>(t.colsum_partial_elems);
+    t.tn_slab_elems = gemm_tn_slab_elems();
+    t.tn_slab = c.take<float>(t.tn_slab_elems);
     t.norm_partial = c.take<float>(1024);
     const size_t Mp = (R + 63) / 64 * 64;
     t.tn_scratch_elems = tr_path ? 0 : (size_t)2 * (2 * M) * Mp;
@@ -215,8 +215,21 @@ int SmdEngine::bind_schedule(const float* coef, const float* sqrt_ap, const floa
 
 int SmdEngine::refresh_weights(hipStream_t st) {
   SMD_ARG_CHECK(params_ && wpack_, "refresh_weights: parameters not bound");
-  for (DenseP* p : all_dense_)
-    RC(launch_recast_weight(P(p->w_off), p->K, p->N, wpack_ + p->W_off, p->Np, wpack_ + p->Wt_off, p->Kp, st));
+  size_t i = 0;
+  while (i < all_dense_.size()) {                 // one launch per <= SMD_RECAST_MAX weights (normally one)
+    RecastTable t;
+    t.n = 0;
+    uint32_t tiles = 0;
+    for (; i < all_dense_.size() && t.n < SMD_RECAST_MAX; ++i) {
+      const DenseP* p = all_dense_[i];
+      RecastEntry& e = t.e[t.n++];
+      e.w_off = (uint32_t)p->w_off; e.K = (uint32_t)p->K; e.N = (uint32_t)p->N;
+      e.W_off = (uint32_t)p->W_off; e.ldw = (uint32_t)p->Np; e.Wt_off = (uint32_t)p->Wt_off; e.ldwt = (uint32_t)p->Kp;
+      e.tile_start = tiles;
+      tiles += (uint32_t)(((p->K + 63) / 64) * ((p->N + 63) / 64));
+    }
+    RC(launch_recast_all(params_, wpack_, t, (int)tiles, st));
+  }
   return 0;
 }
 
@@ -228,11 +241,13 @@ int SmdEngine::dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmE
 
 int SmdEngine::dense_bwd(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bf16_t* dX,
                          int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st) {
-  // dW = X^T dY ; db = colsum(dY) ; dX = dY W^T (* act'(aux))
-  bf16_t* scratch = tr_path ? W.zero_page : W.tn_scratch;
-  const size_t scratch_elems = tr_path ? 128 : W.tn_scratch_elems;
-  RC(launch_gemm_tn(X, ldx, dY, ldy, M, p.K, p.N, G(p.w_off), p.N, scratch, scratch_elems, tr_path, st));
-  RC(launch_colsum_bf16(dY, ldy, M, p.N, G(p.b_off), W.colsum_partial, W.colsum_partial_elems, st));
+  // dW = X^T dY and db = colsum(dY) in one launch ; dX = dY W^T (* act'(aux))
+  TnLaunch t;
+  t.X = X; t.ldx = ldx; t.dY = dY; t.ldy = ldy; t.Mrows = M; t.Kd = p.K; t.N = p.N;
+  t.out = G(p.w_off); t.ldo = p.N; t.bias_out = G(p.b_off);
+  t.zero_page = W.zero_page; t.slab = W.tn_slab; t.slab_elems = W.tn_slab_elems;
+  t.scratch = W.tn_scratch; t.scratch_elems = W.tn_scratch_elems; t.tr_path = tr_path;
+  RC(launch_gemm_tn(t, st));
   if (dX) {
     GemmEpilogue ep;
     ep.out_bf16 = dX; ep.ld_outb = ld_dx;

@@ -1,4 +1,5 @@
-// bf16 MFMA weight-gradient GEMM, "TN" form:  dW[Kd,N] (+)= sum_m X[m,Kd] * dY[m,N]
+// bf16 MFMA weight-gradient GEMM, "TN" form:
+//     dW[Kd,N] = sum_m X[m,Kd] * dY[m,N]      and      db[N] = sum_m dY[m,N]
 //
 // Backward of every nn.Dense on the eps-net path (the value_and_grad of train_ncsn.py:282-283).
 // Both operands are stored with the contraction index m as the ROW index, so MFMA fragments
@@ -9,14 +10,18 @@
 //     (a 256-B row = 16 lanes), two LDS buffers, counted vmcnt, raw s_barrier (as gemm_nt).
 //   * fragment = two ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of
 //     row (i>>2), 8-byte column chunk (i&3) of a [4 m][16 col] block and receives column i of
-//     those 4 rows (cdna_hip_programming.md section 2 / T10).
+//     those 4 rows (cdna_hip_programming.md section 2 / T10; verified by smd_probe_tr_read).
 //   * 16-byte chunk c of LDS row r is stored at chunk c ^ ((r&3)<<2) (source-side swizzle +
 //     matching XOR on the read): the 4 rows of one transpose block land in 4 different 64-B
 //     bank quarters, so a 32-lane service group is conflict free.
-//   * split-K over m across blockIdx.y with fp32 atomics when the output has few tiles
-//     (all 128-wide weights); rows past Mrows are sourced from a caller-provided zero page.
+//   * the bias gradient rides on the matrix cores: the workgroups of the first Kd-tile row run
+//     one extra MFMA per B fragment with an all-ones A fragment, whose every output row is the
+//     column sum of dY -- no separate reduction kernels.
+//   * split-K over m (blockIdx.y) for the 128-wide weights writes fp32 partial tiles to slabs
+//     with 16-byte stores; a second kernel adds the slabs in a fixed order (deterministic, no
+//     atomics, no memsets).  Rows past Mrows are sourced from a caller-provided zero page.
 //
-// Fallback (tr_path = 0): explicit bf16 transposes into scratch + the NT kernel.
+// Fallback (tr_path = 0): explicit bf16 transposes into scratch + the NT kernel + column sums.
 #include "smd_kernels.h"
 
 namespace {
@@ -25,6 +30,7 @@ constexpr int BT = 128;          // output tile edge (both Kd and N)
 constexpr int BKM = 64;          // m rows per K-tile
 constexpr int TILE_BYTES = BKM * BT * 2;   // 16 KiB
 constexpr int BUF_BYTES = 2 * TILE_BYTES;
+constexpr int STAGE_LD = 132;
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
@@ -64,40 +70,39 @@ __device__ __forceinline__ void tr_read_kstep(unsigned a0, unsigned a1, unsigned
 
 template <int... Es> struct IntSeq {};
 typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
-
-__device__ __forceinline__ void store_one(float a, int row, int col, int Kd, int N, float* out, int ldo,
-                                          int atomic) {
-  if (row < Kd && col < N) {
-    float* o = out + (size_t)row * ldo + col;
-    if (atomic) atomicAdd(o, a);
-    else *o = a;
-  }
-}
+// 32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
 template <int... Es>
-__device__ __forceinline__ void store_tile(const f32x16_t& acc, int row0, int col, int Kd, int N,
-                                           float* out, int ldo, int atomic, IntSeq<Es...>) {
-  (store_one(acc[Es], row0 + (Es & 3) + 8 * (Es >> 2), col, Kd, N, out, ldo, atomic), ...);
+__device__ __forceinline__ void stage_tile(const f32x16_t& acc, float* stage, int row0, int col, IntSeq<Es...>) {
+  ((stage[(row0 + (Es & 3) + 8 * (Es >> 2)) * STAGE_LD + col] = acc[Es]), ...);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
-    const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ dY, int ldy, int Mrows, int Kd,
-    int N, float* __restrict__ out, int ldo, int tiles_n, int ktiles_per_split, int atomic,
-    const bf16_t* __restrict__ zero_page) {
+struct TnArgs {
+  const bf16_t* X; int ldx;
+  const bf16_t* dY; int ldy;
+  int Mrows, Kd, N;
+  float* out; int ldo;            // final dW (nsplit == 1) ...
+  float* bias_out;                // ... and db, may be null
+  float* slab; size_t slab_stride; // nsplit > 1: partials slab[split][Kd*N (+N)], row stride N
+  int tiles_n, ktiles_per_split, nsplit;
+  const bf16_t* zero_page;
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
 
   const int tile = blockIdx.x;
-  const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
+  const int tk = tile / a.tiles_n, tn = tile - tk * a.tiles_n;
   const int kd0 = tk * BT, n0 = tn * BT;
-  const int kt_begin = blockIdx.y * ktiles_per_split;
-  const int total_kt = (Mrows + BKM - 1) / BKM;
-  int kt_end = kt_begin + ktiles_per_split;
-  kt_end = kt_end < total_kt ? kt_end : total_kt;
-  if (kt_begin >= kt_end) return;
+  const int kt_begin = blockIdx.y * a.ktiles_per_split;
+  const int total_kt = (a.Mrows + BKM - 1) / BKM;
+  int kt_end = kt_begin + a.ktiles_per_split;
+  kt_end = kt_end < total_kt ? kt_end : total_kt;      // launcher guarantees kt_begin < kt_end
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wc = w & 1;
+  const bool do_bias = (a.bias_out != nullptr) && tk == 0 && wr == 0;     // wave-uniform
 
   // ---- DMA sources: wave w piece j covers LDS rows (w*4+j)*4 .. +4 ; 16 lanes per 256-B row.
   // LDS chunk (lane&15) of row r receives global chunk (lane&15) ^ ((r&3)<<2); r&3 == lane>>4.
@@ -105,8 +110,8 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
   int xcol = kd0 + src_chunk * 8;
   int ycol = n0 + src_chunk * 8;
   // keep the 16-B read inside the row: columns past the end only feed discarded outputs
-  xcol = xcol + 8 <= ldx ? xcol : 0;
-  ycol = ycol + 8 <= ldy ? ycol : 0;
+  xcol = xcol + 8 <= a.ldx ? xcol : 0;
+  ycol = ycol + 8 <= a.ldy ? ycol : 0;
   const int piece_row = w * 16 + (lane >> 4);     // + j*4
 
   auto issue_tile = [&](int kt, int buf) {
@@ -114,13 +119,13 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = kt * BKM + piece_row + j * 4;
-      const bf16_t* src = m < Mrows ? X + (size_t)m * ldx + xcol : zero_page + (lane & 15) * 8;
+      const bf16_t* src = m < a.Mrows ? a.X + (size_t)m * a.ldx + xcol : a.zero_page + (lane & 15) * 8;
       glds16(src, base + j * 1024);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = kt * BKM + piece_row + j * 4;
-      const bf16_t* src = m < Mrows ? dY + (size_t)m * ldy + ycol : zero_page + (lane & 15) * 8;
+      const bf16_t* src = m < a.Mrows ? a.dY + (size_t)m * a.ldy + ycol : a.zero_page + (lane & 15) * 8;
       glds16(src, base + TILE_BYTES + j * 1024);
     }
   };
@@ -138,13 +143,19 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
     b_col[i] = ((((cb >> 4) ^ (rsub << 2)) << 4) | (cb & 15)) + TILE_BYTES;
   }
 
-  f32x16_t acc[2][2];
+  f32x16_t acc[2][2], acc_b[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_b[i][e] = 0.0f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  }
+  bf16x8_t ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
   const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)smem;
   issue_tile(kt_begin, 0);
@@ -165,7 +176,11 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
     __builtin_amdgcn_sched_barrier(0);                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bfr[j].v, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bfr[j].v, acc[i][j], 0, 0, 0); \
+    if (do_bias) {                                                                              \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
+        acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[j].v, acc_b[j], 0, 0, 0);  \
+    }
     SMD_TN_KSTEP(0)
     SMD_TN_KSTEP(4096)
     SMD_TN_KSTEP(8192)
@@ -175,11 +190,90 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(
     __builtin_amdgcn_s_barrier();
   }
 
+  // ---- destination of this block's partial: final buffers or its split's slab
+  float* dst = a.out;
+  float* dst_b = a.bias_out;
+  int ld = a.ldo;
+  if (a.nsplit > 1) {
+    dst = a.slab + (size_t)blockIdx.y * a.slab_stride;
+    dst_b = dst + (size_t)a.Kd * a.N;
+    ld = a.N;
+  }
   const int kh = lane >> 5;
-  store_tile(acc[0][0], kd0 + wr * 64 + 4 * kh, n0 + wc * 64 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
-  store_tile(acc[0][1], kd0 + wr * 64 + 4 * kh, n0 + wc * 64 + 32 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
-  store_tile(acc[1][0], kd0 + wr * 64 + 32 + 4 * kh, n0 + wc * 64 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
-  store_tile(acc[1][1], kd0 + wr * 64 + 32 + 4 * kh, n0 + wc * 64 + 32 + (lane & 31), Kd, N, out, ldo, atomic, Seq16{});
+  if (do_bias && kh == 0) {                       // row 0 of the ones-MFMA = column sums
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + (lane & 31);
+      if (col < a.N) dst_b[col] = acc_b[j][0];
+    }
+  }
+  // ---- dW tile through LDS: 64 rows per pass, each lane stores 4 consecutive columns
+  float* stage = reinterpret_cast<float*>(smem);
+  const bool vec = (ld % 4 == 0) && ((((size_t)dst) & 15) == 0);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (p > 0) __syncthreads();
+    if (wr == p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          stage_tile(acc[i][j], stage, i * 32 + 4 * kh, wc * 64 + j * 32 + (lane & 31), Seq16{});
+    }
+    __syncthreads();
+    const int c4 = (tid & 31) * 4;
+    const int col = n0 + c4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rs = (tid >> 5) + 8 * i;
+      const int row = kd0 + p * 64 + rs;
+      if (row < a.Kd && col < a.N) {
+        const float4 v = *reinterpret_cast<const float4*>(stage + rs * STAGE_LD + c4);
+        float* o = dst + (size_t)row * ld + col;
+        if (vec && col + 3 < a.N) {
+          *reinterpret_cast<float4*>(o) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < a.N) o[e] = vv[e];
+        }
+      }
+    }
+  }
+}
+
+// out[i] = sum_s slab[s][i] for i < count (dW then db), fixed order
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, size_t stride, int nsplit,
+                                                           size_t n_w, float* __restrict__ out_w, int n_b,
+                                                           float* __restrict__ out_b) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const size_t total = n_w + (out_b ? (size_t)n_b : 0);
+  if (i >= total) return;
+  if (i + 3 < n_w && (stride % 4 == 0) && (n_w % 4 == 0)) {
+    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+    int s = 0;
+    for (; s + 1 < nsplit; s += 2) {
+      const float4 u = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
+      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)(s + 1) * stride + i);
+      s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+      s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+    }
+    if (s < nsplit) {
+      const float4 u = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
+      s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
+    }
+    *reinterpret_cast<float4*>(out_w + i) = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  } else {
+    for (int e = 0; e < 4; ++e) {
+      const size_t k = i + e;
+      if (k >= total) break;
+      float acc = 0.f;
+      for (int s = 0; s < nsplit; ++s) acc += slab[(size_t)s * stride + k];
+      if (k < n_w) out_w[k] = acc;
+      else out_b[k - n_w] = acc;
+    }
+  }
 }
 
 // ---- bf16 transpose through LDS: out[c][r] = in[r][c]
@@ -200,7 +294,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   }
 }
 
-// ---- column sums (bias gradients), two deterministic stages
+// ---- column sums (fallback-path bias gradients), two deterministic stages
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const bf16_t* __restrict__ dY, int ldy, int rows,
                                                             int cols, int rows_per_chunk,
                                                             float* __restrict__ partial) {
@@ -266,46 +360,63 @@ int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out
   return 0;
 }
 
-// tr_path: scratch[0..128) must be a ZEROED page on entry (source for rows past Mrows); the
-// launcher never writes it.
-int launch_gemm_tn(const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int Mrows, int Kd, int N,
-                   float* out, int ldo, bf16_t* scratch, size_t scratch_elems, int tr_path,
-                   hipStream_t st) {
-  SMD_ARG_CHECK(X && dY && out, "gemm_tn: null operand");
-  SMD_ARG_CHECK(Mrows > 0 && Kd > 0 && N > 0, "gemm_tn: bad shape");
-  SMD_ARG_CHECK(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= 8 && ldy >= 8, "gemm_tn: ldx/ldy must be multiples of 8");
-  if (tr_path) {
-    SMD_ARG_CHECK(scratch && scratch_elems >= 128, "gemm_tn: needs a 128-element zero page in scratch");
-    const int tiles_k = (Kd + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
+size_t gemm_tn_slab_elems() { return (size_t)576 * BT * BT + 65536; }
+
+int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
+  SMD_ARG_CHECK(t.X && t.dY && t.out, "gemm_tn: null operand");
+  SMD_ARG_CHECK(t.Mrows > 0 && t.Kd > 0 && t.N > 0, "gemm_tn: bad shape");
+  SMD_ARG_CHECK(t.ldx % 8 == 0 && t.ldy % 8 == 0 && t.ldx >= 8 && t.ldy >= 8 && t.ldo >= t.N,
+                "gemm_tn: ldx/ldy must be multiples of 8, ldo >= N");
+  if (t.tr_path) {
+    SMD_ARG_CHECK(t.zero_page, "gemm_tn: needs a 128-element zeroed bf16 page");
+    const int tiles_k = (t.Kd + BT - 1) / BT, tiles_n = (t.N + BT - 1) / BT;
     const int tiles = tiles_k * tiles_n;
-    const int total_kt = (Mrows + BKM - 1) / BKM;
-    int nsplit = (512 + tiles - 1) / tiles;
-    if (nsplit > total_kt) nsplit = total_kt;
-    if (nsplit < 1) nsplit = 1;
+    const int total_kt = (t.Mrows + BKM - 1) / BKM;
+    const size_t stride = ((size_t)t.Kd * t.N + t.N + 3) / 4 * 4;
+    int nsplit = 1;
+    if (tiles < 192 && t.slab && t.ldo == t.N) {      // skinny outputs: split the m range
+      nsplit = (384 + tiles - 1) / tiles;
+      if (nsplit > total_kt) nsplit = total_kt;
+      const size_t cap = t.slab_elems / stride;
+      if ((size_t)nsplit > cap) nsplit = (int)cap;
+      if (nsplit < 1) nsplit = 1;
+    }
     const int per = (total_kt + nsplit - 1) / nsplit;
     nsplit = (total_kt + per - 1) / per;
-    if (nsplit > 1) {
-      hipError_t e = hipMemset2DAsync(out, (size_t)ldo * 4, 0, (size_t)N * 4, Kd, st);
-      if (e != hipSuccess) { smd_set_error("gemm_tn: memset2d: %s", hipGetErrorString(e)); return (int)e; }
-    }
-    hipLaunchKernelGGL(gemm_tn_128x128_kernel, dim3(tiles, nsplit), dim3(256), 0, st, X, ldx, dY, ldy,
-                       Mrows, Kd, N, out, ldo, tiles_n, per, nsplit > 1 ? 1 : 0, scratch);
+    TnArgs a;
+    a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
+    a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t.slab; a.slab_stride = stride;
+    a.tiles_n = tiles_n; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t.zero_page;
+    hipLaunchKernelGGL(gemm_tn_128x128_kernel, dim3(tiles, nsplit), dim3(256), 0, st, a);
     SMD_LAUNCH_CHECK();
+    if (nsplit > 1) {
+      const size_t n_w = (size_t)t.Kd * t.N;
+      const size_t total = n_w + (t.bias_out ? t.N : 0);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, t.slab,
+                         stride, nsplit, n_w, t.out, t.N, t.bias_out);
+      SMD_LAUNCH_CHECK();
+    }
     return 0;
   }
   // ---- fallback: explicit transposed copies, then the NT kernel (contraction = Mrows padded to 64)
-  const int Mp = (Mrows + 63) / 64 * 64;
-  SMD_ARG_CHECK(scratch && scratch_elems >= (size_t)(Kd + N) * Mp, "gemm_tn: scratch too small for fallback");
-  bf16_t* Xt = scratch;
-  bf16_t* Yt = scratch + (size_t)Kd * Mp;
-  int rc = launch_transpose_bf16(X, ldx, Mrows, Kd, Xt, Mp, st);
+  const int Mp = (t.Mrows + 63) / 64 * 64;
+  SMD_ARG_CHECK(t.scratch && t.scratch_elems >= (size_t)(t.Kd + t.N) * Mp, "gemm_tn: scratch too small for fallback");
+  bf16_t* Xt = t.scratch;
+  bf16_t* Yt = t.scratch + (size_t)t.Kd * Mp;
+  int rc = launch_transpose_bf16(t.X, t.ldx, t.Mrows, t.Kd, Xt, Mp, st);
   if (rc) return rc;
-  rc = launch_transpose_bf16(dY, ldy, Mrows, N, Yt, Mp, st);
+  rc = launch_transpose_bf16(t.dY, t.ldy, t.Mrows, t.N, Yt, Mp, st);
   if (rc) return rc;
   GemmEpilogue ep;
-  ep.out_f32 = out;
-  ep.ld_out = ldo;
-  return launch_gemm_nt(Xt, Mp, Yt, Mp, Kd, N, Mp, ep, st);
+  ep.out_f32 = t.out;
+  ep.ld_out = t.ldo;
+  rc = launch_gemm_nt(Xt, Mp, Yt, Mp, t.Kd, t.N, Mp, ep, st);
+  if (rc) return rc;
+  if (t.bias_out) {
+    SMD_ARG_CHECK(t.slab && t.slab_elems >= (size_t)128 * t.N, "gemm_tn: fallback bias needs the slab workspace");
+    rc = launch_colsum_bf16(t.dY, t.ldy, t.Mrows, t.N, t.bias_out, t.slab, t.slab_elems, st);
+  }
+  return rc;
 }
 
 // ---- debug probe: what does ds_read_b64_tr_b16 return for a linear image with lane address lane*8 ?

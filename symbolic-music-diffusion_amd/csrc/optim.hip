@@ -132,7 +132,46 @@ __global__ __launch_bounds__(256) void recast_weight_kernel(const float* __restr
   }
 }
 
+// every Dense kernel of the model in ONE launch: block -> (weight, 64x64 tile) through a small table
+__global__ __launch_bounds__(256) void recast_all_kernel(const float* __restrict__ params, bf16_t* __restrict__ wpack,
+                                                         RecastTable t) {
+  __shared__ float tile[64][65];
+  int wi = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n; ++i)
+    if ((int)blockIdx.x >= (int)t.e[i].tile_start) wi = i;
+  const RecastEntry e = t.e[wi];
+  const int local = blockIdx.x - e.tile_start;
+  const int tiles_n = (e.N + 63) / 64;
+  const int k0 = (local / tiles_n) * 64, n0 = (local % tiles_n) * 64;
+  const float* w = params + e.w_off;
+  bf16_t* W = wpack + e.W_off;
+  bf16_t* Wt = wpack + e.Wt_off;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int k = k0 + i, n = n0 + tx;
+    float v = 0.f;
+    if (k < (int)e.K && n < (int)e.N) {
+      v = w[(size_t)k * e.N + n];
+      W[(size_t)k * e.ldw + n] = f2bf(v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int n = n0 + i, k = k0 + tx;
+    if (n < (int)e.N && k < (int)e.K) Wt[(size_t)n * e.ldwt + k] = f2bf(tile[tx][i]);
+  }
+}
+
 }  // namespace
+
+int launch_recast_all(const float* params, bf16_t* wpack, const RecastTable& t, int total_tiles, hipStream_t st) {
+  SMD_ARG_CHECK(params && wpack && t.n > 0 && t.n <= SMD_RECAST_MAX && total_tiles > 0, "recast_all: bad arguments");
+  hipLaunchKernelGGL(recast_all_kernel, dim3(total_tiles), dim3(256), 0, st, params, wpack, t);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
 
 static int norm_blocks_for(size_t n) {
   size_t b = (n / 4 + 255) / 256;

@@ -36,14 +36,24 @@ struct GemmEpilogue {
 int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
                    const GemmEpilogue& ep, hipStream_t st);
 
-// dW[Kd,N] (+)= sum_m X[m,Kd] * dY[m,N]   (wgrad; both operands row index = contraction index m)
-// X [Mrows][ldx] bf16, dY [Mrows][ldy] bf16, out fp32 [Kd][ldo]. Mrows % 32 == 0.
-// accumulate=0 requires the output to be zeroed by the caller when split-K > 1 (the launcher
-// zeroes it itself with a memset node).  `tr_path`: 1 = LDS transpose-read kernel, 0 = explicit
-// transposed copies through `scratch` (>= (Kd+N)*Mrows bf16) and the NT kernel.
-int launch_gemm_tn(const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int Mrows, int Kd, int N,
-                   float* out, int ldo, bf16_t* scratch, size_t scratch_elems, int tr_path,
-                   hipStream_t st);
+// dW[Kd,N] = sum_m X[m,Kd] * dY[m,N] and (optionally) db[N] = sum_m dY[m,N]   (wgrad; both operands
+// have the contraction index m as the row index).  X [Mrows][ldx] bf16, dY [Mrows][ldy] bf16,
+// out fp32 [Kd][ldo].  tr_path 1: LDS transpose-read kernel (needs `zero_page`: 128 zeroed bf16, and
+// `slab`: gemm_tn_slab_elems() floats for deterministic split-K partials); tr_path 0: explicit
+// transposed copies through `scratch` (>= (Kd+N)*roundup(Mrows,64) bf16) + the NT kernel.
+struct TnLaunch {
+  const bf16_t* X = nullptr; int ldx = 0;
+  const bf16_t* dY = nullptr; int ldy = 0;
+  int Mrows = 0, Kd = 0, N = 0;
+  float* out = nullptr; int ldo = 0;
+  float* bias_out = nullptr;
+  const bf16_t* zero_page = nullptr;
+  float* slab = nullptr; size_t slab_elems = 0;
+  bf16_t* scratch = nullptr; size_t scratch_elems = 0;
+  int tr_path = 1;
+};
+size_t gemm_tn_slab_elems();
+int launch_gemm_tn(const TnLaunch& t, hipStream_t st);
 int launch_transpose_bf16(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out,
                           hipStream_t st);
 // out[n] = sum_m dY[m][n]  (bias gradient), deterministic two-stage reduction via `partial`
@@ -177,6 +187,11 @@ int launch_adam_clip_ema(const AdamArgs& a, hipStream_t st);
 int launch_recast_weight(const float* w, int K_in, int N_out, bf16_t* W, int ldw, bf16_t* Wt, int ldwt,
                          hipStream_t st);
 
+// all Dense kernels in one launch (table passed by value: <= SMD_RECAST_MAX weights per launch)
+#define SMD_RECAST_MAX 60
+struct RecastEntry { uint32_t w_off, K, N, W_off, ldw, Wt_off, ldwt, tile_start; };
+struct RecastTable { int n; RecastEntry e[SMD_RECAST_MAX]; };
+int launch_recast_all(const float* params, bf16_t* wpack, const RecastTable& t, int total_tiles, hipStream_t st);
 int launch_probe_tr_read(const bf16_t* image, bf16_t* out, hipStream_t st);   // gemm_tn.hip debug probe
 int launch_pos_encoding(float* pe, int S, int channels, hipStream_t st);      // models/shared.py:36-48
 // generic small helpers

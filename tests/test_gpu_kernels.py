@@ -122,15 +122,26 @@ def test_gemm_tn(L, dev, tr_path, M, Kd, N, ldx):
     X, Y = bf(X), bf(Y)
     ref = X[:, :Kd].double().t() @ Y[:, :N].double()
     out = torch.full((Kd, N), float("nan"), device=dev)
+    db = torch.full((N,), float("nan"), device=dev)
     Mp = (M + 63) // 64 * 64
+    zero = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+    slab = torch.full((int(L.smd_gemm_tn_slab_elems()),), float("nan"), device=dev)
     scratch = torch.zeros(max(128, (Kd + N) * Mp if not tr_path else 128), dtype=torch.bfloat16, device=dev)
     Xd, Yd = X.to(dev), Y.to(dev)
-    ck(L, L.smd_gemm_bf16_tn(P(Xd), ldx, P(Yd), ldy, M, Kd, N, P(out), N, P(scratch), scratch.numel(),
-                             tr_path, st()))
+    ck(L, L.smd_gemm_bf16_tn(P(Xd), ldx, P(Yd), ldy, M, Kd, N, P(out), N, P(db), P(zero), P(slab), slab.numel(),
+                             P(scratch), scratch.numel(), tr_path, st()))
     torch.cuda.synchronize()
     e = rel(out, ref)
-    print(f"gemm_tn tr={tr_path} M={M} Kd={Kd} N={N}: rel {e:.2e}")
-    assert e < 3e-5            # fp32 accumulation (split-K atomics reorder the sum)
+    eb = rel(db, Y[:, :N].double().sum(0))
+    print(f"gemm_tn tr={tr_path} M={M} Kd={Kd} N={N}: rel dW {e:.2e} db {eb:.2e}")
+    assert e < 3e-5            # fp32 accumulation
+    assert eb < 3e-5
+    if tr_path:                # split-K slabs are reduced in a fixed order: bitwise reproducible
+        out2 = torch.empty_like(out)
+        ck(L, L.smd_gemm_bf16_tn(P(Xd), ldx, P(Yd), ldy, M, Kd, N, P(out2), N, P(db), P(zero), P(slab), slab.numel(),
+                                 P(scratch), scratch.numel(), tr_path, st()))
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
 
 
 @pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),

@@ -67,8 +67,12 @@ def main():
         for (M, Kd, N) in [(R, 2048, 2048), (R, 128, 2048), (R, 2048, 128), (R, 128, 384), (R, 128, 128), (256, 512, 4096)]:
             X, Y = bf(M, Kd), bf(M, N)
             out = torch.empty(Kd, N, device=dev)
+            db = torch.empty(N, device=dev)
+            zero = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+            slab = torch.empty(int(L.smd_gemm_tn_slab_elems()), device=dev)
             scratch = torch.zeros(max(128, (Kd + N) * M if not tr else 128), dtype=torch.bfloat16, device=dev)
             f = lambda: lib.check(L.smd_gemm_bf16_tn(X.data_ptr(), Kd, Y.data_ptr(), N, M, Kd, N, out.data_ptr(), N,
+                                                     db.data_ptr(), zero.data_ptr(), slab.data_ptr(), slab.numel(),
                                                      scratch.data_ptr(), scratch.numel(), tr, st))
             rec(f"gemm_tn(tr={tr})", [M, Kd, N], timeit(f, a.reps), flops=2.0 * M * Kd * N)
     # ---- LayerNorm
