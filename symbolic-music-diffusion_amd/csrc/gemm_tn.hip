@@ -243,19 +243,23 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
   }
 }
 
-// out[i] = sum_s slab[s][i] for i < count (dW then db), fixed order
+// out[i] = sum_s slab[s][i] (dW then db).  64 float4 columns x 4 slab-slices per block; each thread
+// adds its slabs in a fixed order and the 4 slices are combined in a fixed order: deterministic.
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, size_t stride, int nsplit,
                                                            size_t n_w, float* __restrict__ out_w, int n_b,
                                                            float* __restrict__ out_b) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const size_t total = n_w + (out_b ? (size_t)n_b : 0);
-  if (i >= total) return;
-  if (i + 3 < n_w && (stride % 4 == 0) && (n_w % 4 == 0)) {
-    float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
-    int s = 0;
-    for (; s + 1 < nsplit; s += 2) {
+  const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  const bool in = i < total;
+  const bool vec = in && (i + 3 < total);
+  if (vec) {
+    int s = slice;
+    for (; s + 4 < nsplit; s += 8) {
       const float4 u = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
-      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)(s + 1) * stride + i);
+      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)(s + 4) * stride + i);
       s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
       s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
     }
@@ -263,15 +267,23 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
       const float4 u = *reinterpret_cast<const float4*>(slab + (size_t)s * stride + i);
       s0.x += u.x; s0.y += u.y; s0.z += u.z; s0.w += u.w;
     }
-    *reinterpret_cast<float4*>(out_w + i) = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
-  } else {
+  } else if (in) {
+    float t[4] = {0, 0, 0, 0};
+    for (int s = slice; s < nsplit; s += 4)
+      for (int e = 0; e < 4; ++e)
+        if (i + e < total) t[e] += slab[(size_t)s * stride + i + e];
+    s0 = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  red[slice][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  __syncthreads();
+  if (slice == 0 && in) {
+    const float4 a0 = red[0][lane], a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
+    const float r[4] = {(a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                        (a0.w + a1.w) + (a2.w + a3.w)};
     for (int e = 0; e < 4; ++e) {
       const size_t k = i + e;
-      if (k >= total) break;
-      float acc = 0.f;
-      for (int s = 0; s < nsplit; ++s) acc += slab[(size_t)s * stride + k];
-      if (k < n_w) out_w[k] = acc;
-      else out_b[k - n_w] = acc;
+      if (k < n_w) out_w[k] = r[e];
+      else if (k < total) out_b[k - n_w] = r[e];
     }
   }
 }
@@ -360,7 +372,7 @@ int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out
   return 0;
 }
 
-size_t gemm_tn_slab_elems() { return (size_t)576 * BT * BT + 65536; }
+size_t gemm_tn_slab_elems() { return (size_t)640 * BT * BT + 65536; }
 
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
   SMD_ARG_CHECK(t.X && t.dY && t.out, "gemm_tn: null operand");
@@ -374,8 +386,9 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     const int total_kt = (t.Mrows + BKM - 1) / BKM;
     const size_t stride = ((size_t)t.Kd * t.N + t.N + 3) / 4 * 4;
     int nsplit = 1;
-    if (tiles < 192 && t.slab && t.ldo == t.N) {      // skinny outputs: split the m range
-      nsplit = (384 + tiles - 1) / tiles;
+    if (tiles < 512 && t.slab && t.ldo == t.N) {      // keep >= 2 workgroups per CU: split the m range
+      nsplit = (512 + tiles - 1) / tiles;
+      if (nsplit > 32) nsplit = 32;
       if (nsplit > total_kt) nsplit = total_kt;
       const size_t cap = t.slab_elems / stride;
       if ((size_t)nsplit > cap) nsplit = (int)cap;
@@ -392,7 +405,7 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     if (nsplit > 1) {
       const size_t n_w = (size_t)t.Kd * t.N;
       const size_t total = n_w + (t.bias_out ? t.N : 0);
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total / 4 + 256) / 256)), dim3(256), 0, st, t.slab,
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t.slab,
                          stride, nsplit, n_w, t.out, t.N, t.bias_out);
       SMD_LAUNCH_CHECK();
     }

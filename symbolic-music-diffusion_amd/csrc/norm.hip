@@ -148,88 +148,80 @@ struct LnBwdDev {
 };
 
 template <int D>
-__global__ __launch_bounds__(256, 2) void layernorm_bwd_kernel(LnBwdDev a) {
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdDev a) {
   typedef RowLayout<D> L;
   constexpr int PL = L::PER_LANE;
-  // [0..3] = gamma, beta, film scale, film shift of this row group (read per row from LDS instead of
-  // living in 4*PL registers); [4..7] = cross-wave reduction scratch
-  __shared__ __attribute__((aligned(16))) float sp[8][D];
+  __shared__ float red[4][D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int grp = blockIdx.x;
   const int r_begin = grp * a.group_rows;
   int r_end = r_begin + a.group_rows;
   r_end = r_end < a.f.rows ? r_end : a.f.rows;
   const bool film = a.f.film_scale != nullptr;
-  {
-    const int frow = film ? (a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample) : 0;
-    for (int c = threadIdx.x; c < D; c += 256) {
-      sp[0][c] = a.f.gamma[c];
-      sp[1][c] = a.f.beta[c];
-      sp[2][c] = film ? a.f.film_scale[(size_t)frow * a.f.ld_film + c] : 1.0f;
-      sp[3][c] = film ? a.f.film_shift[(size_t)frow * a.f.ld_film + c] : 0.0f;
-    }
-  }
-  __syncthreads();
 
+  float g[PL], b[PL], sc[PL], sh[PL];
+  load_vec<D>(a.f.gamma, lane, g);
+  load_vec<D>(a.f.beta, lane, b);
+  if (film) {
+    const int frow = a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample;
+    load_vec<D>(a.f.film_scale + (size_t)frow * a.f.ld_film, lane, sc);
+    load_vec<D>(a.f.film_shift + (size_t)frow * a.f.ld_film, lane, sh);
+  }
   float acc_dg[PL], acc_db[PL], acc_dsc[PL], acc_dsh[PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) acc_dg[i] = acc_db[i] = acc_dsc[i] = acc_dsh[i] = 0.f;
 
   for (int row = r_begin + w; row < r_end; row += 4) {
-    float x[PL], dy[PL];                       // become xhat / d(xhat) in place
-    asm volatile("" ::: "memory");             // keep the sp[] reads inside the loop (no LICM into 4*PL registers)
+    float x[PL], dy[PL];
     load_row<D>(a.f.x, a.f.x_bf16, row, lane, x);
     load_row<D>(nullptr, a.dout, row, lane, dy);
     float mean, rstd;
     row_stats<D>(x, mean, rstd);
     float s1 = 0.f, s2 = 0.f;
+    float xh[PL], dxh[PL];
 #pragma unroll
     for (int i = 0; i < PL; ++i) {
-      const int c = L::col(lane, i);
-      const float gi = sp[0][c], bi = sp[1][c];
-      const float xh = (x[i] - mean) * rstd;
-      const float n = xh * gi + bi;
+      xh[i] = (x[i] - mean) * rstd;
+      const float n = xh[i] * g[i] + b[i];
       float d = dy[i];
       if (film) {
-        const float sci = sp[2][c];
-        const float pre = sci * n + sp[3][c];
+        const float pre = sc[i] * n + sh[i];
         if (a.f.swish) d *= swish_gradf_(pre);
         acc_dsc[i] += d * n;
         acc_dsh[i] += d;
-        d *= sci;
+        d *= sc[i];
       } else if (a.f.swish) {
         d *= swish_gradf_(n);
       }
-      acc_dg[i] += d * xh;
+      acc_dg[i] += d * xh[i];
       acc_db[i] += d;
-      const float dxh = d * gi;
-      s1 += dxh;
-      s2 += dxh * xh;
-      x[i] = xh;
-      dy[i] = dxh;
-      if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (registers)
+      dxh[i] = d * g[i];
+      s1 += dxh[i];
+      s2 += dxh[i] * xh[i];
     }
     s1 = wave_sum(s1) * (1.0f / D);
     s2 = wave_sum(s2) * (1.0f / D);
+    float dx[PL];
 #pragma unroll
-    for (int i = 0; i < PL; ++i) dy[i] = rstd * (dy[i] - s1 - x[i] * s2);
+    for (int i = 0; i < PL; ++i) dx[i] = rstd * (dxh[i] - s1 - xh[i] * s2);
     if (a.dres) {
-      load_row<D>(a.dres, nullptr, row, lane, x);
+      float r[PL];
+      load_row<D>(a.dres, nullptr, row, lane, r);
 #pragma unroll
-      for (int i = 0; i < PL; ++i) dy[i] += x[i];
+      for (int i = 0; i < PL; ++i) dx[i] += r[i];
     }
-    if (a.dx_f32) store_row_f32<D>(a.dx_f32, row, lane, dy);
-    if (a.dx_bf16) store_row_bf16<D>(a.dx_bf16, row, lane, dy);
+    if (a.dx_f32) store_row_f32<D>(a.dx_f32, row, lane, dx);
+    if (a.dx_bf16) store_row_bf16<D>(a.dx_bf16, row, lane, dx);
   }
 
   // ---- combine the 4 waves' column sums through LDS, one quantity at a time
   auto combine = [&](float (&v)[PL], float* dst, int accumulate) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < PL; ++i) sp[4 + w][L::col(lane, i)] = v[i];
+    for (int i = 0; i < PL; ++i) red[w][L::col(lane, i)] = v[i];
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += 256) {
-      const float s = sp[4][c] + sp[5][c] + sp[6][c] + sp[7][c];
+      const float s = red[0][c] + red[1][c] + red[2][c] + red[3][c];
       if (dst) dst[c] = accumulate ? dst[c] + s : s;
     }
   };
@@ -242,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_kernel(LnBwdDev a) {
   }
 }
 
+// dgamma[c] += sum_g partial[g][0][c] ; dbeta likewise (fixed order -> deterministic)
 // 64 columns x 4 group-slices per block: many independent loads in flight instead of one long
 // dependent chain per column (the one-thread-per-column version was latency-bound at ~65 us).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int ngroups, int D,
