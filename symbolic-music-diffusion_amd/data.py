@@ -1,0 +1,136 @@
+"""Data in / out of the hot path: latent batches in, ``.pkl`` sample files out.
+
+The reference feeds tf.data TFRecords (input_pipeline.py:113-235); TensorFlow is not on the target
+image and BASELINE's workloads are synthetic, so this module provides
+  * ``SyntheticLatents``   clip(0.25*N(0,1), -1, 1) batches with the dataset attributes the
+                           reference loops rely on (.examples, .min, .max)   [BASELINE.md section 2]
+  * ``ArrayLatents``       the same interface over a NumPy array / .npy / .pkl of latents
+  * ``normalize_dataset`` / ``slice_transform`` / ``inverse_data_transform`` (input_pipeline.py:
+    36-48,78-110) and ``save`` / ``load`` (utils/data_utils.py:30-41, pickle protocol 4)
+TFRecord ingestion is a "next" row.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Iterator, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def save(obj, path: str) -> None:
+    """utils/data_utils.py:30-35."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump(obj, f, protocol=4)
+
+
+def load(path: str):
+    """utils/data_utils.py:38-41."""
+    with open(path, "rb") as f:
+        return pickle.load(f)
+
+
+def normalize_dataset(batch, data_min, data_max):
+    """input_pipeline.py:36-40."""
+    batch = (batch - data_min) / (data_max - data_min)
+    return 2.0 * batch - 1.0
+
+
+def slice_transform(batch, slice_idx=None, dim_weights=None):
+    """input_pipeline.py:43-48 (NumPy gather instead of tf.gather)."""
+    if dim_weights is not None:
+        batch = batch * dim_weights
+    if slice_idx is not None:
+        batch = np.take(batch, slice_idx, axis=-1)
+    return batch
+
+
+def inverse_data_transform(batch, normalize=True, pca=None, data_min=0.0, data_max=1.0, slice_idx=None,
+                           dim_weights=None, out_channels=512):
+    """input_pipeline.py:78-110.  The non-selected latent dims are filled with an unseeded
+    np.random.randn exactly like the reference (:102-105)."""
+    batch = np.asarray(batch)
+    if normalize:
+        batch = (batch + 1.0) / 2.0
+        batch = (data_max - data_min) * batch + data_min
+    if pca is not None:
+        batch = pca.inverse_transform(batch)
+    if slice_idx is not None:
+        transformed = np.random.randn(*batch.shape[:-1], out_channels)
+        transformed[..., slice_idx] = batch
+        batch = transformed
+    if dim_weights is not None:
+        batch = batch / dim_weights
+    return batch
+
+
+class ArrayLatents:
+    """Batched view of an in-memory latent array with the attributes train_ncsn.py reads from its
+    tf.data datasets: ``examples`` = batches per epoch (:359,381), ``min`` / ``max`` (:424-431)."""
+
+    def __init__(self, array: np.ndarray, batch_size: int, data_min: float = -1.0, data_max: float = 1.0,
+                 drop_remainder: bool = True, device: Optional[str] = None, rank: int = 0, world_size: int = 1):
+        array = np.ascontiguousarray(array, dtype=np.float32)
+        if world_size > 1:                      # disjoint contiguous shard per rank
+            per = len(array) // world_size
+            array = array[rank * per:(rank + 1) * per]
+        self.array = torch.from_numpy(array)
+        if device is not None:
+            self.array = self.array.to(device)   # resident in HBM: no per-step H2D copy
+        self.batch_size = batch_size
+        n = len(array)
+        self.examples = n // batch_size if drop_remainder else -(-n // batch_size)
+        self.min, self.max = data_min, data_max
+
+    @property
+    def sample_shape(self):
+        return tuple(self.array.shape[1:])
+
+    def __iter__(self) -> Iterator[torch.Tensor]:
+        for i in range(self.examples):
+            yield self.array[i * self.batch_size:(i + 1) * self.batch_size]
+
+    def __len__(self):
+        return self.examples
+
+    def take_examples(self, n: int) -> np.ndarray:
+        return self.array[:n].cpu().numpy()
+
+
+class SyntheticLatents(ArrayLatents):
+    """x0 = clip(0.25*N(0,1), -1, 1), torch CPU generator seed 1234 (+rank) -- BASELINE.md section 2."""
+
+    def __init__(self, sample_shape: Sequence[int], num_examples: int, batch_size: int, seed: int = 1234,
+                 device: Optional[str] = None, rank: int = 0, world_size: int = 1):
+        g = torch.Generator().manual_seed(seed + rank)
+        per = num_examples // world_size
+        x = torch.clamp(0.25 * torch.randn(per, *sample_shape, generator=g), -1.0, 1.0)
+        super().__init__(x.numpy(), batch_size, -1.0, 1.0, True, device)
+
+
+def open_dataset(path: str, batch_size: int, sample_shape: Sequence[int], device=None, rank=0, world_size=1,
+                 normalize=True, slice_idx=None, dim_weights=None):
+    """``--dataset`` as {train,eval}.npy / .pkl arrays of raw latents (N, *shape_raw).  TFRecords
+    (input_pipeline.py:182-207) are not readable without TensorFlow."""
+    out = []
+    for split in ("train", "eval"):
+        arr = None
+        for ext in (".npy", ".pkl"):
+            f = os.path.join(path, split + ext)
+            if os.path.exists(f):
+                arr = np.load(f) if ext == ".npy" else load(f)
+                break
+        if arr is None:
+            raise FileNotFoundError(
+                f"{path}/{split}.npy|.pkl not found. TFRecord datasets need TensorFlow (not on this image); "
+                "convert them to .npy or pass --synthetic.")
+        arr = slice_transform(np.asarray(arr, np.float32), slice_idx, dim_weights)
+        out.append(arr)
+    dmin, dmax = float(out[0].min()), float(out[0].max())       # train min/max like data_utils.py:128-156
+    sets = []
+    for arr in out:
+        a = normalize_dataset(arr, dmin, dmax) if normalize else arr
+        sets.append(ArrayLatents(a.reshape(len(a), *sample_shape), batch_size, dmin, dmax, True, device, rank, world_size))
+    return sets[0], sets[1]

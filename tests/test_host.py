@@ -1,0 +1,191 @@
+"""CPU tests of the host logic: flag surface, configs, data transforms, checkpoint naming and the
+data-parallel gradient exchange (gloo, world_size 2)."""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import ddpm_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+def test_flag_surface_defaults_match_reference_table():
+    import smd_amd.flags as F
+    fl = F.make_flags(include_sample=True)
+    # SURVEY section 5 "Flag surface to keep"
+    expect = dict(seed=0, loss="dsm", continuous_noise=True, learning_rate=3e-4, batch_size=128, epochs=10,
+                  max_steps=None, early_stopping=False, grad_clip=1.0, lr_gamma=0.98, lr_schedule_interval=10000,
+                  architecture="TransformerDDPM", num_layers=6, num_heads=8, num_mlp_layers=2, mlp_dims=2048,
+                  sigma_begin=1.0, sigma_end=1e-2, schedule_type="geometric", num_sigmas=15, ld_steps=100,
+                  ld_epsilon=2e-6, sampling="ald", ema=True, mu=0.999, denoise=True, data_shape=["2"], problem="toy",
+                  dataset="./output/mix2d", pca_ckpt="", slice_ckpt="", dim_weights_ckpt="", normalize=True,
+                  logging_freq=100, snapshot_freq=5000, snapshot_sampling=True, eval_samples=3000,
+                  checkpoints_to_keep=50, save_ckpt=True, model_dir="./save/ncsn", verbose=True, sample_seed=1,
+                  sampling_dir="samples", sample_size=1000, compute_metrics=False, compute_final_only=False,
+                  flush=True, animate=False, infill=False, interpolate=False)
+    for k, v in expect.items():
+        assert getattr(fl, k) == v, k
+    assert len(F.TRAIN_FLAGS) == 41 and len(F.SAMPLE_FLAGS) == 9
+
+
+def test_flag_syntax_variants(tmp_path):
+    import smd_amd.flags as F
+    inner = tmp_path / "inner.cfg"
+    inner.write_text("--ema=False\n--num_layers=3\n\n# comment\n--data_shape=32,512  \n")
+    outer = tmp_path / "outer.cfg"
+    outer.write_text(f"--flagfile={inner}\n--num_layers=8\n--nosnapshot_sampling\n--continuous_noise\n")
+    fl = F.make_flags(True)
+    rest = fl.parse([f"--flagfile={outer}", "--learning_rate", "1e-3", "--noverbose", "--max_steps=7", "pos"])
+    assert rest == ["pos"]
+    assert fl.ema is False and fl.num_layers == 8 and fl.data_shape == ["32", "512"]      # later wins
+    assert fl.snapshot_sampling is False and fl.verbose is False and fl.max_steps == 7 and fl.learning_rate == 1e-3
+    assert fl.is_present("ema") and not fl.is_present("mu")
+    for bad in (["--nosuchflag=1"], ["--loss=foo"], ["--num_layers=abc"], ["--flagfile=/no/such/file"], ["--noseed"]):
+        with pytest.raises(F.FlagError):
+            F.make_flags(True).parse(bad)
+    assert "--noema" in fl.flags_into_string()
+
+
+def test_shipped_configs_parse_and_match_reference():
+    import smd_amd.flags as F
+    ours = sorted(glob.glob(os.path.join(ROOT, "configs", "ddpm-*.cfg")))
+    assert len(ours) >= 6
+    cwd = os.getcwd()
+    for f in ours:
+        os.chdir(ROOT)
+        a = F.make_flags(True)
+        a.parse([f"--flagfile=configs/{os.path.basename(f)}"])
+        assert a.loss == "ddpm" and a.sampling == "ddpm" and a.num_sigmas == 1000 and a.schedule_type == "linear"
+        ref = os.path.join(REF, "configs", os.path.basename(f))
+        if os.path.exists(ref):
+            os.chdir(REF)
+            b = F.make_flags(True)
+            b.parse([f"--flagfile=configs/{os.path.basename(f)}"])
+            assert a.flag_values_dict() == b.flag_values_dict(), f
+    os.chdir(cwd)
+    if os.path.isdir(os.path.join(REF, "configs")):       # every reference flagfile parses (surface test)
+        os.chdir(REF)
+        for f in glob.glob("configs/**/*.cfg", recursive=True):
+            if os.path.basename(f).startswith("mdn"):     # train_mdn.py flagfiles: a different flag set
+                continue
+            F.make_flags(True).parse([f"--flagfile={f}"])
+        os.chdir(cwd)
+
+
+def test_data_transforms_match_oracle(tmp_path):
+    from smd_amd import data
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-3, 5, size=(4, 32, 512)).astype(np.float32)
+    idx = np.sort(rng.choice(512, 42, replace=False))
+    s = data.slice_transform(x, idx)
+    assert s.shape == (4, 32, 42) and np.array_equal(s, x[..., idx])
+    n = data.normalize_dataset(s, -3.0, 5.0)
+    assert np.allclose(n, O.normalize_dataset(s, -3.0, 5.0)) and n.min() >= -1 and n.max() <= 1
+    np.random.seed(7)
+    ours = data.inverse_data_transform(n, True, None, -3.0, 5.0, idx)
+    np.random.seed(7)
+    filler = np.random.randn(4, 32, 512)
+    ref = O.inverse_data_transform(n, True, -3.0, 5.0, idx, filler=filler)
+    assert ours.shape == (4, 32, 512) and ours.dtype == np.float64 and np.array_equal(ours, ref)
+    assert np.allclose(ours[..., idx], s, atol=1e-5)
+    p = tmp_path / "a" / "b.pkl"
+    data.save(ours, str(p))
+    with open(p, "rb") as f:
+        assert np.array_equal(pickle.load(f), ours)
+    assert np.array_equal(data.load(str(p)), ours)
+    ds = data.SyntheticLatents((32, 512), 64, 16)
+    assert ds.examples == 4 and ds.min == -1.0 and ds.max == 1.0
+    b = next(iter(ds))
+    assert tuple(b.shape) == (16, 32, 512) and float(b.abs().max()) <= 1.0
+    a0 = data.SyntheticLatents((32, 8), 64, 16, rank=0, world_size=2)
+    a1 = data.SyntheticLatents((32, 8), 64, 16, rank=1, world_size=2)
+    assert a0.examples == 2 and not torch.equal(next(iter(a0)), next(iter(a1)))
+
+
+def test_early_stopping_and_rng_split():
+    from smd_amd import ncsn
+    from smd_amd.train_utils import EarlyStopping
+    es = EarlyStopping(patience=1)
+    ok, es = es.update(1.0)
+    assert ok and es.best_metric == 1.0
+    ok, es = es.update(1.5)
+    assert not ok and es.patience_count == 1 and not es.should_stop
+    ok, es = es.update(1.5)
+    assert not ok and es.should_stop
+    a, b, c = ncsn.split(ncsn.PRNGKey(0), num=3)
+    assert len({a.seed, b.seed, c.seed}) == 3 and ncsn.split(ncsn.PRNGKey(0), 3)[1] == b
+    with pytest.raises(ValueError):
+        ncsn.config_from_kwargs("ConvNCSN", (32, 512), {})
+    with pytest.raises(ValueError):
+        ncsn.config_from_kwargs("TransformerDDPM", (512,), {})
+    cfg = ncsn.config_from_kwargs("DenseDDPM", (512,), dict(num_layers=6, num_heads=8, num_mlp_layers=2, mlp_dims=2048))
+    assert cfg.sample_shape == (512,)                     # accepts-and-ignores the transformer kwargs
+
+
+def test_shard_bounds_cover_exactly():
+    from smd_amd.trainer import shard_bounds
+    for n in (0, 1, 7, 1000, 1001):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(b - a for a, b in spans) - min(b - a for a, b in spans) <= 1
+
+
+# ------------------------------------------------------------------ data-parallel exchange (gloo, 2 ranks)
+def _dp_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from smd_amd.trainer import GradComm
+    torch.set_num_threads(1)
+    comm = GradComm()
+    assert comm.world_size == world and comm.rank == rank
+    # the trainer's convention: each rank's gradient is already scaled by 1/(GLOBAL batch * S * C), the
+    # all-reduce is a SUM over two buckets split at the engine's head offset -> the global-batch gradient
+    cfg = O.NetConfig(data_channels=8, num_layers=1, num_heads=4, num_mlp_layers=1, mlp_dims=256)
+    p = O.init_params(cfg, 0, torch.float64)
+    betas = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
+    g = torch.Generator().manual_seed(5)
+    B = 4
+    x0 = torch.randn(B, 32, 8, generator=g, dtype=torch.float64)
+    labels = torch.randint(1, 1001, (B,), generator=g).numpy()
+    eps = torch.randn(B, 32, 8, generator=g, dtype=torch.float64)
+
+    def grads(sl):
+        leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        per = O.diffusion_loss(x0[sl], O.make_model(leaf, cfg), betas, labels[sl], eps[sl], "none")
+        (per.sum() / B).backward()                      # local sum / GLOBAL batch
+        return torch.cat([leaf[k].grad.reshape(-1) for k, _ in O.param_spec(cfg)])
+
+    full = grads(slice(0, B))
+    half = B // world
+    mine = grads(slice(rank * half, (rank + 1) * half)).clone()
+    head = int(mine.numel() * 0.6)                      # any split point: buckets are independent
+    comm.reduce_async(mine[head:])
+    comm.reduce_async(mine[:head])
+    comm.wait()
+    assert torch.allclose(mine, full, rtol=1e-10, atol=1e-14), float((mine - full).abs().max())
+    flat = torch.full((10,), float(rank))
+    comm.broadcast_params(flat)
+    assert float(flat.sum()) == 0.0
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+
+
+def test_data_parallel_gradient_exchange_gloo(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
