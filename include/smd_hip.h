@@ -118,6 +118,12 @@ int smd_engine_init_state(smd_engine* e, float* x, uint32_t seed_lo, uint32_t se
 int smd_engine_load_state(smd_engine* e, const float* x, void* stream);
 int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream);
 
+/* process-wide kernel-selection knob for benchmark A/B runs (defaults = fast paths).
+ * "gemm_nt256": 1 = large Dense GEMMs use the 256x256 8-phase kernel (default), 0 = 128-wide tiles only,
+ *               2 = every shape with M,N % 256 == 0 and K % 128 == 0 (tests);
+ * "gemm_nt256_variant": schedule variant of that kernel (0 default). */
+int smd_set_tuning(const char* key, int value);
+
 /* ---- single kernels (unit-testable ops) ------------------------------------------------------- */
 enum { SMD_EPI_NONE = 0, SMD_EPI_GELU = 1, SMD_EPI_SWISH = 2 };
 /* C[M,N] = act(A[M,K] Bt[N,K]^T + bias) (+ residual); nn.Dense, models/ncsn.py:155 etc. */

@@ -14,9 +14,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "diffusion.hip", "optim.hip",
+SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "diffusion.hip", "optim.hip",
            "engine.hip", "capi.hip"]
-HEADERS = ["smd_common.h", "smd_kernels.h", "engine.h", "rng.h",
+HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h",
            os.path.join("..", "..", "include", "smd_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]

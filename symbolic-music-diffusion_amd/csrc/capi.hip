@@ -140,6 +140,7 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
 }
 
 // ------------------------------------------------------------------ single kernels
+int smd_set_tuning(const char* key, int value) { return smd_tuning_set(key, value); }
 int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, int M, int N, int K, const float* bias,
                      int act, const float* residual, int ld_res, float* out_f32, int ld_out, smd_bf16* out_bf16,
                      int ld_outb, void* stream) {

@@ -19,6 +19,8 @@
 //     stores, which made the K=128 GEMMs store-bound).
 //   * XCD-aware bijective workgroup remap so one XCD's L2 sees a contiguous band of M-tiles.
 #include "smd_kernels.h"
+#include "gemm_epilogue.h"
+#include <string.h>
 
 namespace {
 
@@ -37,92 +39,6 @@ template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_wa
 template <> __device__ __forceinline__ void wait_vmcnt<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-
-__device__ __forceinline__ float epilogue_scalar(float acc, int row, int col, const GemmEpilogue& ep) {
-  float v = ep.alpha * acc;
-  if (ep.bias) v += ep.bias[col];
-  if (ep.pre_bf16) ep.pre_bf16[(size_t)row * ep.ld_pre + col] = f2bf(v);
-  if (ep.act == SMD_ACT_GELU) v = geluf_(v);
-  else if (ep.act == SMD_ACT_SWISH) v = swishf_(v);
-  if (ep.aux_mode != SMD_AUX_NONE) {
-    const float z = bf2f(ep.aux[(size_t)row * ep.ld_aux + col]);
-    v *= (ep.aux_mode == SMD_AUX_GELU_GRAD) ? gelu_gradf_(z) : swish_gradf_(z);
-  }
-  if (ep.res_f32) {
-    const int rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
-    v += ep.res_f32[(size_t)rr * ep.ld_res + col];
-  }
-  if (ep.res_bf16) v += bf2f(ep.res_bf16[(size_t)row * ep.ld_resb + col]);
-  return v;
-}
-
-// 4 consecutive columns of one row; `vec_ok`: every pointer/ld is 4-element aligned and col+3 < N
-__device__ __forceinline__ void epilogue_quad(const float4 a, int row, int col, int N, bool vec_ok,
-                                              const GemmEpilogue& ep) {
-  if (vec_ok) {
-    float v[4] = {ep.alpha * a.x, ep.alpha * a.y, ep.alpha * a.z, ep.alpha * a.w};
-    if (ep.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(ep.bias + col);
-      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    }
-    if (ep.pre_bf16) {
-      bf16x4_t p;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = f2bf(v[i]);
-      *reinterpret_cast<bf16x4_t*>(ep.pre_bf16 + (size_t)row * ep.ld_pre + col) = p;
-    }
-    if (ep.act == SMD_ACT_GELU) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = geluf_(v[i]);
-    } else if (ep.act == SMD_ACT_SWISH) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = swishf_(v[i]);
-    }
-    if (ep.aux_mode != SMD_AUX_NONE) {
-      const bf16x4_t z = *reinterpret_cast<const bf16x4_t*>(ep.aux + (size_t)row * ep.ld_aux + col);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        v[i] *= (ep.aux_mode == SMD_AUX_GELU_GRAD) ? gelu_gradf_(bf2f(z[i])) : swish_gradf_(bf2f(z[i]));
-    }
-    if (ep.res_f32) {
-      const int rr = ep.res_row_mod > 0 ? (row % ep.res_row_mod) : row;
-      const float4 r = *reinterpret_cast<const float4*>(ep.res_f32 + (size_t)rr * ep.ld_res + col);
-      v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-    }
-    if (ep.res_bf16) {
-      const bf16x4_t r = *reinterpret_cast<const bf16x4_t*>(ep.res_bf16 + (size_t)row * ep.ld_resb + col);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] += bf2f(r[i]);
-    }
-    if (ep.out_f32) {
-      float4* o = reinterpret_cast<float4*>(ep.out_f32 + (size_t)row * ep.ld_out + col);
-      if (ep.accumulate) {
-        const float4 c = *o;
-        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-      }
-      *o = make_float4(v[0], v[1], v[2], v[3]);
-    }
-    if (ep.out_bf16) {
-      bf16x4_t p;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = f2bf(v[i]);
-      *reinterpret_cast<bf16x4_t*>(ep.out_bf16 + (size_t)row * ep.ld_outb + col) = p;
-    }
-  } else {
-    const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (col + i < N) {
-        const float v = epilogue_scalar(av[i], row, col + i, ep);
-        if (ep.out_f32) {
-          float* o = ep.out_f32 + (size_t)row * ep.ld_out + col + i;
-          *o = ep.accumulate ? (*o + v) : v;
-        }
-        if (ep.out_bf16) ep.out_bf16[(size_t)row * ep.ld_outb + col + i] = f2bf(v);
-      }
-    }
-  }
-}
 
 template <int... Es> struct IntSeq {};
 typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
@@ -259,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
       const int row = m0 + p * SROWS + rs;
       if (row < M && col < N) {
         const float4 a4 = *reinterpret_cast<const float4*>(stage + rs * STAGE_LD + c4);
-        epilogue_quad(a4, row, col, N, vec_epilogue && (col + 3 < N), ep);
+        smd_epi::epilogue_quad(a4, row, col, N, vec_epilogue && (col + 3 < N), ep);
       }
     }
   }
@@ -273,10 +189,24 @@ void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N
   hipLaunchKernelGGL(gemm_nt_kernel<BM>, dim3(nwg), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, vec, ep);
 }
 
-inline bool al4(const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && ld % 4 == 0); }
-inline bool al4h(const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 7) == 0 && ld % 4 == 0); }
-
 }  // namespace
+
+// process-wide kernel-selection knobs (smd_set_tuning in the C-ABI)
+namespace {
+struct Knob { const char* key; int value; };
+Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}};
+}
+int smd_tuning_set(const char* key, int value) {
+  for (Knob& k : g_knobs)
+    if (key && !strcmp(key, k.key)) { k.value = value; return 0; }
+  smd_set_error("smd_set_tuning: unknown key '%s'", key ? key : "(null)");
+  return -1;
+}
+int smd_tuning_get(const char* key) {
+  for (const Knob& k : g_knobs)
+    if (key && !strcmp(key, k.key)) return k.value;
+  return -1;
+}
 
 int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
                    const GemmEpilogue& ep, hipStream_t st) {
@@ -287,9 +217,8 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
                 "gemm_nt: lda=%d ldb=%d must be >=K and multiples of 8", lda, ldb);
   SMD_ARG_CHECK(ep.out_f32 || ep.out_bf16 || ep.pre_bf16, "gemm_nt: no output");
   SMD_ARG_CHECK(ep.aux_mode == SMD_AUX_NONE || ep.aux, "gemm_nt: aux_mode without aux");
-  const int vec = (al4(ep.bias, 4) && al4(ep.res_f32, ep.ld_res) && al4(ep.out_f32, ep.ld_out) &&
-                   al4h(ep.pre_bf16, ep.ld_pre) && al4h(ep.aux, ep.ld_aux) && al4h(ep.res_bf16, ep.ld_resb) &&
-                   al4h(ep.out_bf16, ep.ld_outb)) ? 1 : 0;
+  if (gemm_nt256_eligible(M, N, K, ep)) return launch_gemm_nt256(A, lda, Bt, ldb, M, N, K, ep, st);
+  const int vec = smd_epi::vec_ok(ep);
   // tile height: keep >= ~256 workgroups on the chip when the output is skinny
   const int tiles_n = (N + BN - 1) / BN;
   const long wg128 = (long)((M + 127) / 128) * tiles_n;

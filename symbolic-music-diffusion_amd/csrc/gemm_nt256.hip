@@ -1,0 +1,313 @@
+// bf16 MFMA GEMM, "NT" form, 256 x 256 x 64 workgroup tile with an 8-phase software pipeline:
+//   C[M,N] = A[M,K] * Bt[N,K]^T  + the fused epilogue of gemm_epilogue.h.
+//
+// This is the kernel for the MFMA-bound GEMMs of the eps-net: the two 2048x2048 Dense layers of every
+// DenseResBlock (reference models/shared.py:65,69 -> 77 % of the forward flops) and their dgrads.
+// Skinny / ragged shapes stay on gemm_nt.hip.
+//
+// gfx950 design (cdna_hip_programming.md section 5, "256^2 8-phase"):
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); every wave owns a contiguous 128 x 64 block of C, held as
+//     2 x 2 quadrants of 64 x 32 (two 32x32 MFMA tiles each) = 128 accumulator registers.
+//   * A K-tile (64 deep) is four 16-KiB half-tiles  B0 A0 B1 A1  (half h of A = the rows every wave needs
+//     for its quadrant row h; same for B), DMA'd HBM/L2 -> LDS with global_load_lds_dwordx4.  Two K-tile
+//     buffers = 128 KiB LDS, one workgroup per CU, two waves per SIMD.
+//   * One K-tile = 4 phases, one per C quadrant: {ds_read the fragments this quadrant still needs, issue ONE
+//     half-tile DMA for a later K-tile, s_barrier, 8 MFMA 32x32x16 under s_setprio(1), s_barrier}.  The two
+//     wave rows run one barrier apart, so on every SIMD one wave is in its MFMA half-phase while the other
+//     reads LDS / issues DMA.  DMAs are retired only by a counted s_waitcnt vmcnt(6) once per K-tile: three
+//     half-tiles stay in flight across every barrier; vmcnt never reaches 0 inside the loop.
+//   * Hazards are closed by construction, not by timing: a half-tile is read one phase after the
+//     (vmcnt, barrier) that retires it, and re-staged only after a barrier that follows the lgkmcnt wait
+//     that retired its reads (order B0 A0 B1 A1 = consumption order).
+//   * LDS rows are 128 B; 16-byte chunk c of row r sits at chunk c ^ ((r>>1)&7): the swizzle is applied on
+//     the per-lane DMA *source* address and again on the ds_read_b128 address (same involution), which makes
+//     the 16-lane read groups of the 32x32x16 A/B fragments conflict-free.
+//   * Epilogue: each wave stages its accumulators through its own slice of the (now free) LDS so that lanes
+//     own 4 consecutive columns: 16-byte loads of bias/residual, 128..256-byte contiguous row stores.
+//   * Bijective XCD-aware workgroup remap (block b runs on XCD b % 8): each XCD's L2 sees a band of M-tiles.
+#include "smd_kernels.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int HALF_BYTES = 128 * TK * 2;          // 16 KiB: 128 rows x 64 bf16
+constexpr int KT_BYTES = 4 * HALF_BYTES;          // B0 A0 B1 A1
+constexpr int SMEM_BYTES = 2 * KT_BYTES;          // 128 KiB
+constexpr int OFF_B0 = 0, OFF_A0 = HALF_BYTES, OFF_B1 = 2 * HALF_BYTES, OFF_A1 = 3 * HALF_BYTES;
+constexpr int SLD = 68;                           // staged epilogue row: 64 floats + 4 pad (272 B)
+constexpr int WAVE_STAGE_BYTES = 32 * SLD * 4;    // 8704 B per wave
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// LDS-DMA of 16 B per lane: source = buffer descriptor base + per-lane voffset + wave-uniform soffset,
+// destination = wave-uniform LDS base + lane*16.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff,
+                                       unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+#define SMD_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define SMD_LGKMCNT(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+#define SMD_PIN() __builtin_amdgcn_sched_barrier(0)
+#define SMD_BAR() __builtin_amdgcn_s_barrier()
+
+typedef const __attribute__((address_space(3))) bf16x8_t* lds_frag_ptr;
+typedef const __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
+
+struct Frags {
+  bf16x8_t a[2][4];    // [m-tile][k-step] of the current A half
+  bf16x8_t b0[4], b1[4];
+};
+
+// `ad[ks]` = LDS address of the lane's chunk for k-step ks in the wave's first row block of a K-tile buffer;
+// `off` (half-tile offset) and the m-tile stride fold into the ds_read immediate (< 64 KiB).
+__device__ __forceinline__ void read_a(Frags& f, const lds_byte_ptr (&ad)[4], int off) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) f.a[mt][ks] = *reinterpret_cast<lds_frag_ptr>(ad[ks] + off + mt * 32 * 128);
+}
+__device__ __forceinline__ void read_b(bf16x8_t (&b)[4], const lds_byte_ptr (&ad)[4], int off) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<lds_frag_ptr>(ad[ks] + off);
+}
+template <int V>
+__device__ __forceinline__ void mma_quadrant(f32x16_t (&acc)[2], const bf16x8_t (&a)[2][4], const bf16x8_t (&b)[4]) {
+  if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+  if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(0);
+}
+
+template <int... Es> struct IntSeq {};
+typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
+// 32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+template <int... Es>
+__device__ __forceinline__ void stage_tile(const f32x16_t& acc, float* stage, int row0, int col, IntSeq<Es...>) {
+  ((stage[(row0 + (Es & 3) + 8 * (Es >> 2)) * SLD + col] = acc[Es]), ...);
+}
+
+// V: schedule variants for A/B runs (bit 0: no explicit lgkmcnt(0) after the phase barrier -- the compiler's own
+// counted waits sit between the MFMAs; bit 1: no s_setprio around the MFMA clusters).
+template <int V>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restrict__ A, int lda,
+                                                         const bf16_t* __restrict__ Bt, int ldb, int M, int N, int K,
+                                                         int tiles_n, int nwg, GemmEpilogue ep) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+
+  const int bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = swz / tiles_n, tn = swz - tm * tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+
+  // ---- DMA sources.  Round j (0/1) of half h: wave w fills LDS rows j*64 + w*8 .. +8 of the half-tile (1 KiB),
+  // 8 lanes per 128-B row; the lane's source chunk is its LDS chunk ^ ((row>>1)&7).
+  //   A half h, LDS row r  <->  global row m0 + (r/64)*128 + h*64 + r%64     (wave row wr reads r in [wr*64, +64))
+  //   B half h, LDS row r  <->  global row n0 + (r/32)*64  + h*32 + r%32     (wave col wc reads r in [wc*32, +32))
+  // Source address = buffer descriptor over the tile's 256-row band + one 32-bit per-lane byte offset (VGPR) + a
+  // wave-uniform byte offset (SGPR): no 64-bit per-lane pointers in the loop.
+  const int lrow = lane >> 3;
+  const int sw_src = ((w & 1) * 4 + (lrow >> 1)) & 7;
+  const int gk = ((lane & 7) ^ sw_src) * 8;
+  const uint32_t a_lane = (uint32_t)(((w * 8 + lrow) * lda + gk) * 2);
+  const uint32_t b_lane = (uint32_t)((((w >> 2) * 64 + (w & 3) * 8 + lrow) * ldb + gk) * 2);
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(A + (size_t)m0 * lda), 0, TM * lda * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<bf16_t*>(Bt + (size_t)n0 * ldb), 0, TN * ldb * 2, 0x00020000);
+  const uint32_t a_round = (uint32_t)(128 * lda * 2), a_half = (uint32_t)(64 * lda * 2);
+  const uint32_t b_round = (uint32_t)(128 * ldb * 2), b_half = (uint32_t)(32 * ldb * 2);
+  unsigned char* lds_w = smem + w * 1024;
+
+#define STAGE_A(buf, h, kt)                                                                       \
+  do {                                                                                            \
+    const uint32_t s_ = (h) * a_half + (uint32_t)(kt) * (TK * 2);                                 \
+    glds16(a_rsrc, a_lane, s_, lds_w + (buf) * KT_BYTES + ((h) ? OFF_A1 : OFF_A0));               \
+    glds16(a_rsrc, a_lane, s_ + a_round, lds_w + (buf) * KT_BYTES + ((h) ? OFF_A1 : OFF_A0) + 8192); \
+  } while (0)
+#define STAGE_B(buf, h, kt)                                                                       \
+  do {                                                                                            \
+    const uint32_t s_ = (h) * b_half + (uint32_t)(kt) * (TK * 2);                                 \
+    glds16(b_rsrc, b_lane, s_, lds_w + (buf) * KT_BYTES + ((h) ? OFF_B1 : OFF_B0));               \
+    glds16(b_rsrc, b_lane, s_ + b_round, lds_w + (buf) * KT_BYTES + ((h) ? OFF_B1 : OFF_B0) + 8192); \
+  } while (0)
+
+  // ---- fragment read addresses: row = (wave base) + (lane&31); chunk (2*ks + kh) ^ ((row>>1)&7).
+  // One address register per (operand, k-step, K-tile buffer): everything else is a ds_read immediate.
+  const int fsw = (lane >> 1) & 7, kh = lane >> 5;
+  lds_byte_ptr lds0 = (lds_byte_ptr)smem;
+  lds_byte_ptr a_ad0[4], a_ad1[4], b_ad0[4], b_ad1[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ko = (lane & 31) * 128 + (((ks * 2 + kh) ^ fsw) << 4);
+    a_ad0[ks] = lds0 + wr * 64 * 128 + ko;
+    b_ad0[ks] = lds0 + wc * 32 * 128 + ko;
+    a_ad1[ks] = a_ad0[ks] + KT_BYTES;
+    b_ad1[ks] = b_ad0[ks] + KT_BYTES;
+    asm volatile("" : "+v"(a_ad1[ks]), "+v"(b_ad1[ks]));   // keep them as registers: +64 KiB does not fit an immediate
+  }
+
+  f32x16_t acc[2][2][2];   // [quadrant row][quadrant col][m-tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.0f;
+  Frags f;
+
+  const int nk = K / TK;   // even, >= 2 (checked by the launcher)
+
+  // ---- prologue: K-tile 0 complete in buffer 0, B0 A0 B1 of K-tile 1 in flight; wave row 1 one barrier behind
+  STAGE_B(0, 0, 0); STAGE_A(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
+  if (wr == 1) SMD_BAR();
+  SMD_VMCNT(4);
+  SMD_BAR();
+  STAGE_B(1, 0, 1); STAGE_A(1, 0, 1); STAGE_B(1, 1, 1);
+  SMD_VMCNT(6);
+  SMD_BAR();
+  SMD_PIN();
+
+  // One K-tile from buffer `cur`; the four DMA slots of its phases are given by the caller.
+#define KTILE(cur, S1, S2, S3, S4, WAIT4)                                                         \
+  do {                                                                                            \
+    /* phase 1: quadrant (0,0) */                                                                 \
+    if constexpr (!(V & 4)) read_b(f.b0, (cur) ? b_ad1 : b_ad0, OFF_B0);                                           \
+    SMD_PIN();                                                                                    \
+    if constexpr (!(V & 4)) read_a(f, (cur) ? a_ad1 : a_ad0, OFF_A0);                                              \
+    if constexpr (!(V & 8)) { S1; }                                                                                           \
+    SMD_LGKMCNT(8);                                                                               \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    if constexpr (!(V & 1)) SMD_LGKMCNT(0);                                                       \
+    SMD_PIN();                                                                                    \
+    mma_quadrant<V>(acc[0][0], f.a, f.b0);                                                           \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    SMD_PIN();                                                                                    \
+    /* phase 2: quadrant (0,1) */                                                                 \
+    if constexpr (!(V & 4)) read_b(f.b1, (cur) ? b_ad1 : b_ad0, OFF_B1);                                           \
+    if constexpr (!(V & 8)) { S2; }                                                                                           \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    if constexpr (!(V & 1)) SMD_LGKMCNT(0);                                                       \
+    SMD_PIN();                                                                                    \
+    mma_quadrant<V>(acc[0][1], f.a, f.b1);                                                           \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    SMD_PIN();                                                                                    \
+    /* phase 3: quadrant (1,0) */                                                                 \
+    if constexpr (!(V & 4)) read_a(f, (cur) ? a_ad1 : a_ad0, OFF_A1);                                              \
+    if constexpr (!(V & 8)) { S3; }                                                                                           \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    if constexpr (!(V & 1)) SMD_LGKMCNT(0);                                                       \
+    SMD_PIN();                                                                                    \
+    mma_quadrant<V>(acc[1][0], f.a, f.b0);                                                           \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    SMD_PIN();                                                                                    \
+    /* phase 4: quadrant (1,1) */                                                                 \
+    if constexpr (!(V & 8)) { S4; }                                                                                           \
+    WAIT4;                                                                                        \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    SMD_PIN();                                                                                    \
+    mma_quadrant<V>(acc[1][1], f.a, f.b1);                                                           \
+    SMD_PIN();                                                                                    \
+    SMD_BAR();                                                                                    \
+    SMD_PIN();                                                                                    \
+  } while (0)
+
+  if constexpr ((V & 4) != 0) {   // ablation (wrong results): fragments read once
+    read_b(f.b0, b_ad0, OFF_B0); read_b(f.b1, b_ad0, OFF_B1); read_a(f, a_ad0, OFF_A0);
+  }
+  int kt = 0;
+  for (; kt < nk - 2; kt += 2) {
+    KTILE(0, STAGE_A(1, 1, kt + 1), STAGE_B(0, 0, kt + 2), STAGE_A(0, 0, kt + 2), STAGE_B(0, 1, kt + 2), SMD_VMCNT(6));
+    KTILE(1, STAGE_A(0, 1, kt + 2), STAGE_B(1, 0, kt + 3), STAGE_A(1, 0, kt + 3), STAGE_B(1, 1, kt + 3), SMD_VMCNT(6));
+  }
+  // last two K-tiles: only the outstanding A1 of the final tile is still to be issued
+  KTILE(0, STAGE_A(1, 1, kt + 1), (void)0, (void)0, (void)0, SMD_VMCNT(0));
+  KTILE(1, (void)0, (void)0, (void)0, (void)0, (void)0);
+  if (wr == 0) SMD_BAR();
+  SMD_PIN();
+#undef KTILE
+#undef STAGE_A
+#undef STAGE_B
+
+  // ---- epilogue: per-wave staging, 4 passes of 32 rows x 64 columns; a lane owns 8 consecutive columns of
+  // rows (lane>>3) + 8*i.  The pass's global operands (aux / residual) are requested before the staging.
+  float* stage = reinterpret_cast<float*>(smem + w * WAVE_STAGE_BYTES);
+  const int c8 = (lane & 7) * 8;
+  const int col = n0 + wc * 64 + c8;
+  const int rbase = m0 + wr * 128 + (lane >> 3);
+  float bias8[8];
+  if (ep.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(ep.bias + col), b1 = *reinterpret_cast<const float4*>(ep.bias + col + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+    bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+#define EPI_PASS(mi, mt)                                                                          \
+  do {                                                                                            \
+    smd_epi::EpiPre8 pre[4];                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+      smd_epi::epi8_prefetch(pre[i], rbase + (mi) * 64 + (mt) * 32 + i * 8, col, ep);             \
+    stage_tile(acc[mi][0][mt], stage, 4 * kh, (lane & 31), Seq16{});                              \
+    stage_tile(acc[mi][1][mt], stage, 4 * kh, 32 + (lane & 31), Seq16{});                         \
+    __builtin_amdgcn_wave_barrier();                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+      const float* sp = stage + (i * 8 + (lane >> 3)) * SLD + c8;                                 \
+      const float4 lo = *reinterpret_cast<const float4*>(sp), hi = *reinterpret_cast<const float4*>(sp + 4); \
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};                              \
+      smd_epi::epi8_apply(v, bias8, pre[i], rbase + (mi) * 64 + (mt) * 32 + i * 8, col, ep);      \
+    }                                                                                             \
+    __builtin_amdgcn_wave_barrier();                                                              \
+  } while (0)
+  EPI_PASS(0, 0); EPI_PASS(0, 1); EPI_PASS(1, 0); EPI_PASS(1, 1);
+#undef EPI_PASS
+}
+
+}  // namespace
+
+bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep) {
+  if (!smd_epi::oct_ok(ep)) return false;
+  const int mode = smd_tuning_get("gemm_nt256");
+  if (mode == 0 || M % TM || N % TN || K % (2 * TK) || K < 2 * TK) return false;
+  if (mode == 2) return true;                  // forced (tests)
+  const long tiles = (long)(M / TM) * (N / TN);
+  return tiles >= 192;     // at least ~3/4 of the 256 CUs busy; smaller grids are better served by 128-wide tiles
+}
+
+int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
+                      const GemmEpilogue& ep, hipStream_t st) {
+  SMD_ARG_CHECK(M % TM == 0 && N % TN == 0 && K % (2 * TK) == 0 && K >= 2 * TK,
+                "gemm_nt256: M=%d N=%d must be multiples of 256 and K=%d a multiple of 128", M, N, K);
+  SMD_ARG_CHECK((size_t)TM * lda * 2 < (1ull << 32) && (size_t)TN * ldb * 2 < (1ull << 32), "gemm_nt256: row band exceeds 4 GiB");
+  const int tiles_m = M / TM, tiles_n = N / TN;
+  const int nwg = tiles_m * tiles_n;
+  SMD_ARG_CHECK(smd_epi::oct_ok(ep), "gemm_nt256: epilogue not supported (alignment / alpha / res_bf16 / accumulate)");
+  switch (smd_tuning_get("gemm_nt256_variant")) {
+    case 1: hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 2: hipLaunchKernelGGL(gemm_nt256_kernel<2>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 3: hipLaunchKernelGGL(gemm_nt256_kernel<3>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 4: hipLaunchKernelGGL(gemm_nt256_kernel<4>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 8: hipLaunchKernelGGL(gemm_nt256_kernel<8>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 12: hipLaunchKernelGGL(gemm_nt256_kernel<12>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    default: hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+  }
+  SMD_LAUNCH_CHECK();
+  return 0;
+}

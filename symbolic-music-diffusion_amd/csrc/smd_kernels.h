@@ -36,6 +36,14 @@ struct GemmEpilogue {
 int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
                    const GemmEpilogue& ep, hipStream_t st);
 
+// 256x256x64 8-phase kernel (gemm_nt256.hip); launch_gemm_nt dispatches to it when eligible and enabled
+bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep);
+int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
+                      const GemmEpilogue& ep, hipStream_t st);
+// process-wide kernel-selection knobs (benchmark A/B; defaults are the fast paths). Keys: "gemm_nt256".
+int smd_tuning_set(const char* key, int value);
+int smd_tuning_get(const char* key);
+
 // dW[Kd,N] = sum_m X[m,Kd] * dY[m,N] and (optionally) db[N] = sum_m dY[m,N]   (wgrad; both operands
 // have the contraction index m as the row index).  X [Mrows][ldx] bf16, dY [Mrows][ldy] bf16,
 // out fp32 [Kd][ldo].  tr_path 1: LDS transpose-read kernel (needs `zero_page`: 128 zeroed bf16, and

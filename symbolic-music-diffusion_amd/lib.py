@@ -73,6 +73,7 @@ _SIGS = {
     "smd_engine_init_state": (C.c_int, [c_void, c_void, c_u32, c_u32, c_u32, c_void]),
     "smd_engine_load_state": (C.c_int, [c_void, c_void, c_void]),
     "smd_engine_sample_step": (C.c_int, [c_void, C.POINTER(SampleIO), c_void]),
+    "smd_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "smd_gemm_bf16_nt": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
     "smd_gemm_bf16_tn": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,

@@ -101,6 +101,59 @@ def test_gemm_nt_epilogues(L, dev):
     assert rel(buf, z + res.double()) < 2e-5
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 256), (256, 512, 1024), (1024, 256, 2048)])
+def test_gemm_nt256_forced(L, dev, M, N, K, variant):
+    """The 256x256 8-phase kernel on small grids (forced), every epilogue input, against fp64."""
+    import smd_amd.lib as lib
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = bf(torch.randn(M, K, generator=g))
+    Bt = bf(torch.randn(N, K, generator=g) * 0.5)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    z = A.double() @ Bt.double().t() + bias.double()
+    Ad, Bd, bd, rd = A.to(dev), Bt.to(dev), bias.to(dev), res.to(dev)
+    lib.check(L.smd_set_tuning(b"gemm_nt256", 2))
+    lib.check(L.smd_set_tuning(b"gemm_nt256_variant", variant))
+    try:
+        out = torch.full((M, N), float("nan"), device=dev)
+        outb = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), 0, None, 0, P(out), N, P(outb), N, st()))
+        out2 = torch.empty(M, N, device=dev)
+        ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), 1, P(rd), N, P(out2), N, None, 0, st()))
+        torch.cuda.synchronize()
+    finally:
+        lib.check(L.smd_set_tuning(b"gemm_nt256", 1))
+        lib.check(L.smd_set_tuning(b"gemm_nt256_variant", 0))
+    e, eb, e2 = rel(out, z), rel(outb.float(), z), rel(out2, O.gelu(z) + res.double())
+    print(f"gemm_nt256 v{variant} {M}x{N}x{K}: rel fp32 {e:.2e} bf16 {eb:.2e} gelu+res {e2:.2e}")
+    assert e < 2e-5 and eb < 4e-3 and e2 < 1e-4
+
+
+def test_gemm_nt256_matches_128_tiles_and_is_deterministic(L, dev):
+    """Full-size DenseResBlock GEMM: the 8-phase kernel vs the 128-wide kernel (same fp32 accumulation order per
+    K-step is not guaranteed -> tolerance), and 6 repeated launches bit-identical (race screen)."""
+    import smd_amd.lib as lib
+    M, N, K = 8192, 2048, 2048
+    g = torch.Generator().manual_seed(11)
+    Ad = bf(torch.randn(M, K, generator=g)).to(dev)
+    Bd = bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bd = torch.randn(N, generator=g).to(dev)
+    outs = []
+    for mode in (0, 1, 1, 1, 1, 1, 1):
+        lib.check(L.smd_set_tuning(b"gemm_nt256", mode))
+        o = torch.empty(M, N, device=dev)
+        ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), 0, None, 0, P(o), N, None, 0, st()))
+        outs.append(o)
+    torch.cuda.synchronize()
+    lib.check(L.smd_set_tuning(b"gemm_nt256", 1))
+    e = rel(outs[1], outs[0])
+    print(f"gemm_nt256 vs 128-tile kernel at {M}x{N}x{K}: rel {e:.2e}")
+    assert e < 1e-5
+    for o in outs[2:]:
+        assert torch.equal(o, outs[1])
+
+
+
 def test_gemm_nt_rejects_bad_k(L, dev):
     import smd_amd.lib as lib
     a = torch.zeros(64, 96, dtype=torch.bfloat16, device=dev)

@@ -34,6 +34,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--json", default="")
+    ap.add_argument("--variants", type=lambda t: [int(x) for x in t.split(",")], default=[0, 1])
+    ap.add_argument("--shapes", default="8192x2048x2048")
+    ap.add_argument("--gemm-ab", action="store_true", help="only the interleaved A/B of the NT GEMM kernels/variants")
     a = ap.parse_args()
     L = lib.get_lib()
     dev = "cuda:0"
@@ -53,6 +56,39 @@ def main():
 
     R = 8192
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+    if a.gemm_ab:
+        # within-process interleaved rounds (guide 5.4 rule 24): 128-wide kernel vs the 256^2 8-phase variants
+        arms = [("nt128", 0, 0)] + [(f"nt256/v{v}", 1, v) for v in a.variants]
+        for spec in a.shapes.split(","):
+            dims, _, epi = spec.partition(":")
+            epi = epi or "b"          # b: bias -> bf16 ; r: bias + fp32 residual -> fp32 ; g: bias + gelu -> bf16
+            M, N, K = (int(v) for v in dims.split("x"))
+            A, Bt = bf(M, K), bf(N, K)
+            bias = torch.zeros(N, device=dev)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            res32 = torch.randn(M, N, device=dev) if epi == "r" else None
+            out32 = torch.empty(M, N, device=dev) if epi == "r" else None
+            if epi == "r":
+                f = lambda: lib.check(L.smd_gemm_bf16_nt(A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), 0,
+                                                         res32.data_ptr(), N, out32.data_ptr(), N, None, 0, st))
+            else:
+                f = lambda: lib.check(L.smd_gemm_bf16_nt(A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(),
+                                                         1 if epi == "g" else 0, None, 0, None, 0, out.data_ptr(), N, st))
+            res = {n: [] for n, _, _ in arms}
+            for _ in range(5):
+                for n, mode, var in arms:
+                    lib.check(L.smd_set_tuning(b"gemm_nt256", 2 if mode else 0))
+                    lib.check(L.smd_set_tuning(b"gemm_nt256_variant", var))
+                    res[n].append(timeit(f, a.reps))
+            for n, _, _ in arms:
+                ms = sorted(res[n])
+                rec(f"gemm_ab:{n}:{epi}", [M, N, K], ms[len(ms) // 2], flops=2.0 * M * N * K)
+                rows[-1]["min_ms"] = round(ms[0], 5)
+        lib.check(L.smd_set_tuning(b"gemm_nt256", 1))
+        lib.check(L.smd_set_tuning(b"gemm_nt256_variant", 0))
+        if a.json:
+            json.dump(rows, open(a.json, "w"), indent=1)
+        return
     # ---- NT GEMMs (forward + dgrad shapes)
     for (M, N, K) in [(R, 2048, 2048), (R, 2048, 128), (R, 128, 2048), (R, 384, 128), (R, 128, 128), (R, 128, 512),
                       (R, 512, 2048), (256, 4096, 512), (1000, 4096, 512)]:
