@@ -121,7 +121,9 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
 /* process-wide kernel-selection knob for benchmark A/B runs (defaults = fast paths).
  * "gemm_nt256": 1 = large Dense GEMMs use the 256x256 8-phase kernel (default), 0 = 128-wide tiles only,
  *               2 = every shape with M,N % 256 == 0 and K % 128 == 0 (tests);
- * "gemm_nt256_variant": schedule variant of that kernel (0 default). */
+ * "gemm_nt256_variant": schedule variant of that kernel (0 default);
+ * "gemm_tn256": 1 = 2048-wide weight gradients use the 256x256 8-phase kernel (default), 0 = 128-wide tiles,
+ *               2 = also on small grids (tests). */
 int smd_set_tuning(const char* key, int value);
 
 /* ---- single kernels (unit-testable ops) ------------------------------------------------------- */

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "norm.hip", "attention.hip", "diffusion.hip", "optim.hip",
+SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "attention.hip", "diffusion.hip", "optim.hip",
            "engine.hip", "capi.hip"]
 HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h",
            os.path.join("..", "..", "include", "smd_hip.h")]

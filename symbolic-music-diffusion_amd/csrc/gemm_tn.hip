@@ -372,7 +372,8 @@ int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out
   return 0;
 }
 
-size_t gemm_tn_slab_elems() { return (size_t)640 * BT * BT + 65536; }
+// room for 4 split partials of a 2048x2048 weight (gemm_tn256) + bias partial rows
+size_t gemm_tn_slab_elems() { return (size_t)4 * 2048 * 2048 + (size_t)1024 * 1024; }
 
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
   SMD_ARG_CHECK(t.X && t.dY && t.out, "gemm_tn: null operand");
@@ -380,6 +381,8 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
   SMD_ARG_CHECK(t.ldx % 8 == 0 && t.ldy % 8 == 0 && t.ldx >= 8 && t.ldy >= 8 && t.ldo >= t.N,
                 "gemm_tn: ldx/ldy must be multiples of 8, ldo >= N");
   if (t.tr_path) {
+    int per256 = 0;
+    if (const int ns256 = gemm_tn256_plan(t, &per256)) return launch_gemm_tn256(t, ns256, per256, st);
     SMD_ARG_CHECK(t.zero_page, "gemm_tn: needs a 128-element zeroed bf16 page");
     const int tiles_k = (t.Kd + BT - 1) / BT, tiles_n = (t.N + BT - 1) / BT;
     const int tiles = tiles_k * tiles_n;

@@ -40,7 +40,7 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
 bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep);
 int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
                       const GemmEpilogue& ep, hipStream_t st);
-// process-wide kernel-selection knobs (benchmark A/B; defaults are the fast paths). Keys: "gemm_nt256".
+// process-wide kernel-selection knobs (benchmark A/B; defaults are the fast paths). Keys: "gemm_nt256", "gemm_nt256_variant", "gemm_tn256".
 int smd_tuning_set(const char* key, int value);
 int smd_tuning_get(const char* key);
 
@@ -61,6 +61,9 @@ struct TnLaunch {
   int tr_path = 1;
 };
 size_t gemm_tn_slab_elems();
+// 256x256 8-phase wgrad kernel (gemm_tn256.hip): plan returns nsplit (0 = not eligible)
+int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split);
+int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st);
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st);
 int launch_transpose_bf16(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out,
                           hipStream_t st);

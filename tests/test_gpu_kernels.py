@@ -197,6 +197,41 @@ def test_gemm_tn(L, dev, tr_path, M, Kd, N, ldx):
         assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("M,Kd,N,ldx,ldy", [(512, 256, 256, 256, 256), (1000, 512, 256, 512, 320), (4130, 256, 768, 264, 768),
+                                             (8192, 2048, 512, 2048, 512), (8192, 2048, 2048, 2048, 2048)])
+def test_gemm_tn256(L, dev, M, Kd, N, ldx, ldy):
+    """256x256 8-phase wgrad kernel (forced on small grids): ragged M (descriptor zero-fill), padded leading
+    dimensions, balanced bias partials, split-K slabs; vs fp64 and vs the 128-wide kernel; bitwise repeatable."""
+    import smd_amd.lib as lib
+    g = torch.Generator().manual_seed(M + Kd + N)
+    X = torch.zeros(M, ldx)
+    X[:, :Kd] = torch.randn(M, Kd, generator=g)
+    Y = torch.zeros(M, ldy)
+    Y[:, :N] = torch.randn(M, N, generator=g) * 0.1 + 0.01
+    X, Y = bf(X), bf(Y)
+    ref = X[:, :Kd].double().t() @ Y[:, :N].double()
+    refb = Y[:, :N].double().sum(0)
+    zero = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+    slab = torch.full((int(L.smd_gemm_tn_slab_elems()),), float("nan"), device=dev)
+    scratch = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+    Xd, Yd = X.to(dev), Y.to(dev)
+    outs = []
+    for mode in (2, 2, 0):
+        lib.check(L.smd_set_tuning(b"gemm_tn256", mode))
+        out = torch.full((Kd, N), float("nan"), device=dev)
+        db = torch.full((N,), float("nan"), device=dev)
+        ck(L, L.smd_gemm_bf16_tn(P(Xd), ldx, P(Yd), ldy, M, Kd, N, P(out), N, P(db), P(zero), P(slab), slab.numel(),
+                                 P(scratch), scratch.numel(), 1, st()))
+        torch.cuda.synchronize()
+        outs.append((out, db))
+    lib.check(L.smd_set_tuning(b"gemm_tn256", 1))
+    e, eb = rel(outs[0][0], ref), rel(outs[0][1], refb)
+    e128 = rel(outs[0][0], outs[2][0])
+    print(f"gemm_tn256 M={M} Kd={Kd} N={N}: rel dW {e:.2e} db {eb:.2e} vs 128-wide {e128:.2e}")
+    assert e < 3e-5 and eb < 3e-5 and e128 < 3e-5
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),
                                           (512, True, True), (1024, True, False)])
 def test_layernorm_fwd_bwd(L, dev, D, film, swish):

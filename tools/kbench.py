@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--variants", type=lambda t: [int(x) for x in t.split(",")], default=[0, 1])
     ap.add_argument("--shapes", default="8192x2048x2048")
+    ap.add_argument("--tn-ab", action="store_true", help="interleaved A/B of the wgrad kernels")
     ap.add_argument("--gemm-ab", action="store_true", help="only the interleaved A/B of the NT GEMM kernels/variants")
     a = ap.parse_args()
     L = lib.get_lib()
@@ -56,6 +57,27 @@ def main():
 
     R = 8192
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+    if a.tn_ab:
+        for (M, Kd, N) in [(R, 2048, 2048), (R, 2048, 512), (4 * R, 2048, 2048)]:
+            X, Y = bf(M, Kd), bf(M, N)
+            out = torch.empty(Kd, N, device=dev)
+            db = torch.empty(N, device=dev)
+            zero = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+            slab = torch.empty(int(L.smd_gemm_tn_slab_elems()), device=dev)
+            scratch = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+            f = lambda: lib.check(L.smd_gemm_bf16_tn(X.data_ptr(), Kd, Y.data_ptr(), N, M, Kd, N, out.data_ptr(), N,
+                                                     db.data_ptr(), zero.data_ptr(), slab.data_ptr(), slab.numel(),
+                                                     scratch.data_ptr(), scratch.numel(), 1, st))
+            res = {0: [], 1: []}
+            for _ in range(5):
+                for mode in (0, 1):
+                    lib.check(L.smd_set_tuning(b"gemm_tn256", mode))
+                    res[mode].append(timeit(f, a.reps))
+            for mode in (0, 1):
+                ms = sorted(res[mode])
+                rec(f"tn_ab:{'tn256' if mode else 'tn128'} (+slab reduce)", [M, Kd, N], ms[2], flops=2.0 * M * Kd * N)
+        lib.check(L.smd_set_tuning(b"gemm_tn256", 1))
+        return
     if a.gemm_ab:
         # within-process interleaved rounds (guide 5.4 rule 24): 128-wide kernel vs the 256^2 8-phase variants
         arms = [("nt128", 0, 0)] + [(f"nt256/v{v}", 1, v) for v in a.variants]
