@@ -80,6 +80,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   NEED(e);
   SMD_ARG_CHECK(key, "set_option: null key");
   if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
+  if (std::string(key) == "side_wgrad") return e->impl.set_side_stream(value);
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;
 }

@@ -61,6 +61,9 @@ struct SampleStepIO {
 class SmdEngine {
  public:
   explicit SmdEngine(const SmdModelDesc& d);
+  ~SmdEngine();
+  SmdEngine(const SmdEngine&) = delete;
+  SmdEngine& operator=(const SmdEngine&) = delete;
   const SmdModelDesc& desc() const { return d_; }
   const std::vector<TensorInfo>& tensors() const { return tensors_; }
   int64_t param_count() const { return n_params_; }
@@ -97,6 +100,12 @@ class SmdEngine {
   const float* pred() const { return W.pred; }
   const float* noise_levels() const { return W.s; }
   int tr_path = 1;                                            // wgrad: 1 LDS transpose-read kernel, 0 fallback
+  // Weight-gradient GEMMs on a low-priority side stream (owned by the engine, created on first use): nothing
+  // on the backward chain consumes dW before the optimiser, so the HBM-heavy wgrad + slab reduce overlap the
+  // dgrad / LayerNorm chain.  Every gradient buffer a side wgrad reads has its own slot (no reuse inside a
+  // step); the side stream is joined at the end of loss_backward().  0 = single stream.
+  int set_side_stream(int enable);
+  int side_wgrad = 0;
 
  private:
   int nblocks() const { return d_.arch == 0 ? d_.num_mlp_layers : d_.num_layers; }
@@ -107,7 +116,9 @@ class SmdEngine {
   int backward_stem(hipStream_t st);
   int dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmEpilogue ep, hipStream_t st);
   int dense_bwd(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bf16_t* dX,
-                int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st);
+                int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st, bool allow_side = false);
+  int wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bool allow_side, hipStream_t st);
+  int join_side(hipStream_t st);
   float* P(int64_t off) const { return params_ + off; }
   float* G(int64_t off) const { return grads_ + off; }
 
@@ -132,6 +143,11 @@ class SmdEngine {
   const float* alphas_prod_ext_ = nullptr;
   float* film_tables_ = nullptr;
   int batch_ = 0, training_ = 0;
+  hipStream_t side_ = nullptr;                 // low-priority wgrad stream (owned)
+  std::vector<hipEvent_t> events_;             // recycled per loss_backward
+  size_t next_event_ = 0;
+  bool side_pending_ = false;
+  hipEvent_t take_event();
 
   struct Work {
     // inputs / outputs of the network
@@ -156,22 +172,24 @@ class SmdEngine {
     float* loss = nullptr;                // [B]
     bf16_t* dpred = nullptr;              // [R][Cp]
     float* dy = nullptr;                  // [R][M]
-    bf16_t* dy_bf16 = nullptr;
+    // gradient buffers that are wgrad operands have one slot per use (side-stream wgrads read them late)
+    std::vector<bf16_t*> dyb;             // [K+1] x [R][M]: trunk gradient entering block k (k = K: from ln_o)
     bf16_t* dA_M = nullptr;               // [R][M]
-    bf16_t* do1 = nullptr;                // [R][M]
+    std::vector<bf16_t*> do1;             // [K] x [R][M]
     float* dh = nullptr;                  // [R][E]
-    bf16_t* dh_bf16 = nullptr;
+    std::vector<bf16_t*> dhb;             // [2L+1] x [R][E]: residual-stream gradient versions
     bf16_t* dA_E = nullptr;               // [R][E]
-    bf16_t* dqkv = nullptr;               // [R][3E]
+    std::vector<bf16_t*> dqkv;            // [L] x [R][3E]
     bf16_t* do_ = nullptr;                // [R][E]
-    bf16_t* dz1 = nullptr;                // [R][M]
+    std::vector<bf16_t*> dz1;             // [L] x [R][M]
     std::vector<float*> dss;              // [B][2M]
     bf16_t* dss_bf16 = nullptr;           // [B][2M]
     bf16_t* dp = nullptr;                 // [B][4F]
     bf16_t* df1 = nullptr;                // [B][4F]
     float* ln_partial = nullptr;
     size_t ln_partial_elems = 0;
-    float* tn_slab = nullptr;             // split-K partial tiles of the wgrad kernel
+    float* tn_slab = nullptr;             // split-K partial tiles of the wgrad kernel (main stream)
+    float* tn_slab_side = nullptr;        // the same for wgrads issued on the side stream
     size_t tn_slab_elems = 0;
     float* norm_partial = nullptr;        // [1024]
     bf16_t* zero_page = nullptr;          // [128]

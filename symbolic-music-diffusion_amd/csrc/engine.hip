@@ -29,6 +29,62 @@ int launch_pos_encoding(float* pe, int S, int channels, hipStream_t st);
 
 // ------------------------------------------------------------------ layout
 SmdEngine::SmdEngine(const SmdModelDesc& d) : d_(d) { build_layout(); }
+SmdEngine::~SmdEngine() {
+  for (hipEvent_t e : events_) (void)hipEventDestroy(e);
+  if (side_) (void)hipStreamDestroy(side_);
+}
+
+int SmdEngine::set_side_stream(int enable) {
+  if (enable && !side_) {
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least priority (numerically largest)
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, lo);
+    if (e != hipSuccess) { smd_set_error("set_side_stream: %s", hipGetErrorString(e)); side_ = nullptr; return (int)e; }
+  }
+  side_wgrad = enable ? 1 : 0;
+  return 0;
+}
+
+hipEvent_t SmdEngine::take_event() {
+  if (next_event_ == events_.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    events_.push_back(e);
+  }
+  return events_[next_event_++];
+}
+
+// dW / db of one Dense.  On the side stream when enabled: the side stream first waits for everything the main
+// stream has enqueued so far (dY is complete), then runs the wgrad with its own slab workspace.
+int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bool allow_side,
+                     hipStream_t st) {
+  TnLaunch t;
+  t.X = X; t.ldx = ldx; t.dY = dY; t.ldy = ldy; t.Mrows = M; t.Kd = p.K; t.N = p.N;
+  t.out = G(p.w_off); t.ldo = p.N; t.bias_out = G(p.b_off);
+  t.zero_page = W.zero_page; t.slab = W.tn_slab; t.slab_elems = W.tn_slab_elems;
+  t.scratch = W.tn_scratch; t.scratch_elems = W.tn_scratch_elems; t.tr_path = tr_path;
+  if (!(allow_side && side_wgrad && side_ && tr_path)) return launch_gemm_tn(t, st);
+  hipEvent_t ev = take_event();
+  SMD_ARG_CHECK(ev, "wgrad: cannot create an event");
+  hipError_t e = hipEventRecord(ev, st);
+  if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
+  if (e != hipSuccess) { smd_set_error("wgrad: event: %s", hipGetErrorString(e)); return (int)e; }
+  t.slab = W.tn_slab_side;
+  side_pending_ = true;
+  return launch_gemm_tn(t, side_);
+}
+
+int SmdEngine::join_side(hipStream_t st) {
+  if (!side_pending_) { next_event_ = 0; return 0; }
+  hipEvent_t ev = take_event();
+  SMD_ARG_CHECK(ev, "join_side: cannot create an event");
+  hipError_t e = hipEventRecord(ev, side_);
+  if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+  if (e != hipSuccess) { smd_set_error("join_side: %s", hipGetErrorString(e)); return (int)e; }
+  side_pending_ = false;
+  next_event_ = 0;
+  return 0;
+}
 
 void SmdEngine::build_layout() {
   const int C = d_.data_channels, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
@@ -153,9 +209,11 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     t.loss = c.take<float>(B);
     t.dpred = c.take<bf16_t>(R * Cp_);
     t.dy = c.take<float>(R * M);
-    t.dy_bf16 = c.take<bf16_t>(R * M);
+    t.dyb.resize(K + 1);
+    for (auto& p : t.dyb) p = c.take<bf16_t>(R * M);
     t.dA_M = c.take<bf16_t>(R * M);
-    t.do1 = c.take<bf16_t>(R * M);
+    t.do1.resize(K);
+    for (auto& p : t.do1) p = c.take<bf16_t>(R * M);
     t.dss.resize(K);
     for (auto& p : t.dss) p = c.take<float>(B * 2 * M);
     t.dss_bf16 = c.take<bf16_t>(B * 2 * M);
@@ -163,16 +221,20 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     t.df1 = c.take<bf16_t>(B * 4 * F);
     if (L > 0) {
       t.dh = c.take<float>(R * E);
-      t.dh_bf16 = c.take<bf16_t>(R * E);
+      t.dhb.resize(2 * L + 1);
+      for (auto& p : t.dhb) p = c.take<bf16_t>(R * E);
       t.dA_E = c.take<bf16_t>(R * E);
-      t.dqkv = c.take<bf16_t>(R * 3 * E);
+      t.dqkv.resize(L);
+      for (auto& p : t.dqkv) p = c.take<bf16_t>(R * 3 * E);
       t.do_ = c.take<bf16_t>(R * E);
-      t.dz1 = c.take<bf16_t>(R * M);
+      t.dz1.resize(L);
+      for (auto& p : t.dz1) p = c.take<bf16_t>(R * M);
     }
     t.ln_partial_elems = ln_bwd_partial_elems((int)R, M > E ? M : E) / (S >= 32 ? 32 : 1) + 2 * (size_t)M;
     t.ln_partial = c.take<float>(t.ln_partial_elems);
     t.tn_slab_elems = gemm_tn_slab_elems();
     t.tn_slab = c.take<float>(t.tn_slab_elems);
+    t.tn_slab_side = c.take<float>(t.tn_slab_elems);
     t.norm_partial = c.take<float>(1024);
     const size_t Mp = (R + 63) / 64 * 64;
     t.tn_scratch_elems = tr_path ? 0 : (size_t)2 * (2 * M) * Mp;
@@ -240,14 +302,9 @@ int SmdEngine::dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmE
 }
 
 int SmdEngine::dense_bwd(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bf16_t* dX,
-                         int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st) {
-  // dW = X^T dY and db = colsum(dY) in one launch ; dX = dY W^T (* act'(aux))
-  TnLaunch t;
-  t.X = X; t.ldx = ldx; t.dY = dY; t.ldy = ldy; t.Mrows = M; t.Kd = p.K; t.N = p.N;
-  t.out = G(p.w_off); t.ldo = p.N; t.bias_out = G(p.b_off);
-  t.zero_page = W.zero_page; t.slab = W.tn_slab; t.slab_elems = W.tn_slab_elems;
-  t.scratch = W.tn_scratch; t.scratch_elems = W.tn_scratch_elems; t.tr_path = tr_path;
-  RC(launch_gemm_tn(t, st));
+                         int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st, bool allow_side) {
+  // dW = X^T dY and db = colsum(dY) (side stream when allowed) ; dX = dY W^T (* act'(aux)) on the main chain
+  RC(wgrad(p, X, ldx, dY, ldy, M, allow_side, st));
   if (dX) {
     GemmEpilogue ep;
     ep.out_bf16 = dX; ep.ld_outb = ld_dx;
@@ -374,11 +431,11 @@ int SmdEngine::backward_head(hipStream_t st) {
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
   const int R = rows(), B = batch_, K = nblocks();
   // out_proj (models/ncsn.py:178): X = ao, dY = dpred
-  RC(dense_bwd(out_proj_, W.ao, M, W.dpred, Cp_, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st));
+  RC(dense_bwd(out_proj_, W.ao, M, W.dpred, Cp_, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
   {
     LnBwdArgs b;
     b.f = ln_args(W.y[K], nullptr, R, ln_o_, params_);
-    b.dout = W.dA_M; b.dx = W.dy; b.dx_bf16 = W.dy_bf16;
+    b.dout = W.dA_M; b.dx = W.dy; b.dx_bf16 = W.dyb[K];
     b.dgamma = G(ln_o_.g_off); b.dbeta = G(ln_o_.b_off);
     b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
     RC(launch_layernorm_bwd(b, st));
@@ -386,25 +443,25 @@ int SmdEngine::backward_head(hipStream_t st) {
   for (int k = K - 1; k >= 0; --k) {
     const FilmResP& p = blk_[k];
     // fc2 of the res block: y[k+1] = ya2 W + b + y[k]
-    RC(dense_bwd(p.r2, W.ya2[k], M, W.dy_bf16, M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st));
+    RC(dense_bwd(p.r2, W.ya2[k], M, W.dyb[k + 1], M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
     {
       LnBwdArgs b;
       b.f = ln_args(nullptr, W.o1[k], R, p.ln2, params_);
       b.f.film_scale = W.ss[k]; b.f.film_shift = W.ss[k] + M; b.f.ld_film = 2 * M; b.f.rows_per_sample = S;
       b.f.swish = 1;
-      b.dout = W.dA_M; b.dx_bf16 = W.do1;
+      b.dout = W.dA_M; b.dx_bf16 = W.do1[k];
       b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 0;
       b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
       RC(launch_layernorm_bwd(b, st));
     }
-    RC(dense_bwd(p.r1, W.ya1[k], M, W.do1, M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st));
+    RC(dense_bwd(p.r1, W.ya1[k], M, W.do1[k], M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
     {
       LnBwdArgs b;
       b.f = ln_args(W.y[k], nullptr, R, p.ln1, params_);
       b.f.film_scale = W.ss[k]; b.f.film_shift = W.ss[k] + M; b.f.ld_film = 2 * M; b.f.rows_per_sample = S;
       b.f.swish = 1;
-      b.dout = W.dA_M; b.dres = W.dy; b.dx = W.dy; b.dx_bf16 = W.dy_bf16;
+      b.dout = W.dA_M; b.dres = W.dy; b.dx = W.dy; b.dx_bf16 = W.dyb[k];
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 1;
       b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
@@ -418,10 +475,10 @@ int SmdEngine::backward_head(hipStream_t st) {
   }
   if (d_.arch == 0) {
     // up (models/ncsn.py:171) and ln_f (:170)
-    RC(dense_bwd(up_, W.af, E, W.dy_bf16, M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st));
+    RC(dense_bwd(up_, W.af, E, W.dyb[0], M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
     LnBwdArgs b;
     b.f = ln_args(W.h_last, nullptr, R, ln_f_, params_);
-    b.dout = W.dA_E; b.dx = W.dh; b.dx_bf16 = W.dh_bf16;
+    b.dout = W.dA_E; b.dx = W.dh; b.dx_bf16 = W.dhb[2 * d_.num_layers];
     b.dgamma = G(ln_f_.g_off); b.dbeta = G(ln_f_.b_off);
     b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
     RC(launch_layernorm_bwd(b, st));
@@ -433,34 +490,38 @@ int SmdEngine::backward_stem(hipStream_t st) {
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims;
   const int R = rows(), B = batch_;
   if (d_.arch != 0) {
-    return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dy_bf16, M, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st);
+    return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dyb[0], M, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
   }
+  // residual-stream gradient versions: dhb[2l+2] enters layer l, dhb[2l+1] after its ln2, dhb[2l] after its ln1
   for (int l = d_.num_layers - 1; l >= 0; --l) {
     const EncLayerP& p = enc_[l];
+    bf16_t* dh_in = W.dhb[2 * l + 2];
+    bf16_t* dh_mid = W.dhb[2 * l + 1];
+    bf16_t* dh_out = W.dhb[2 * l];
     // mlp.fc2: h_out = u W2 + b + h_mid ; dz1 = (dh W2^T) * gelu'(z1)
-    RC(dense_bwd(p.fc2, W.u[l], M, W.dh_bf16, E, R, W.dz1, M, W.z1[l], M, SMD_AUX_GELU_GRAD, st));
-    RC(dense_bwd(p.fc1, W.a2[l], E, W.dz1, M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st));
+    RC(dense_bwd(p.fc2, W.u[l], M, dh_in, E, R, W.dz1[l], M, W.z1[l], M, SMD_AUX_GELU_GRAD, st, true));
+    RC(dense_bwd(p.fc1, W.a2[l], E, W.dz1[l], M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
     {
       LnBwdArgs b;
       b.f = ln_args(W.h_mid[l], nullptr, R, p.ln2, params_);
-      b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = W.dh_bf16;
+      b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_mid;
       b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
       b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
       RC(launch_layernorm_bwd(b, st));
     }
-    RC(dense_bwd(p.out, W.o[l], E, W.dh_bf16, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st));
-    RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv, B, S, E, d_.num_heads, st));
-    RC(dense_bwd(p.qkv, W.a1[l], E, W.dqkv, 3 * E, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st));
+    RC(dense_bwd(p.out, W.o[l], E, dh_mid, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st, true));
+    RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv[l], B, S, E, d_.num_heads, st));
+    RC(dense_bwd(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
     {
       LnBwdArgs b;
       b.f = ln_args(W.h[l], nullptr, R, p.ln1, params_);
-      b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = W.dh_bf16;
+      b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_out;
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
       RC(launch_layernorm_bwd(b, st));
     }
   }
-  return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dh_bf16, E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st);
+  return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dhb[0], E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
 }
 
 int SmdEngine::loss_backward(const float* x0, const int* labels, const float* eps_in, uint32_t seed_lo,
@@ -488,7 +549,7 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     if (stage != 3) RC(backward_head(st));
   }
   if (stage == 0 || stage == 2) RC(backward_stem(st));
-  return 0;
+  return join_side(st);      // every gradient is complete on `st` when this returns (stage 1: the output stage)
 }
 
 int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {

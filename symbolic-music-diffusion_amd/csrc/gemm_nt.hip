@@ -34,11 +34,7 @@ __device__ __forceinline__ void glds16(const bf16_t* g, unsigned char* lds_wave_
   __builtin_amdgcn_global_load_lds((glb_void_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
 
-template <int N_> __device__ __forceinline__ void wait_vmcnt();
-template <> __device__ __forceinline__ void wait_vmcnt<0>() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<6>() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
 
 template <int... Es> struct IntSeq {};
 typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
@@ -48,7 +44,10 @@ __device__ __forceinline__ void stage_tile(const f32x16_t& acc, float* stage, in
   ((stage[(row0 + (Es & 3) + 8 * (Es >> 2)) * STAGE_LD + col] = acc[Es]), ...);
 }
 
-template <int BM>
+// NS = number of LDS K-tile buffers.  2: one tile prefetched ahead (MFMA-bound shapes, 64 KiB at BM = 128).
+// 4 (BM <= 64, K >= 512): three tiles in flight -- the skinny-output GEMMs of the 128-wide encoder run one
+// workgroup per CU with 4 MFMAs per wave per K-tile, so a 2-deep pipeline is bound by the DMA latency.
+template <int BM, int NS>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda,
                                                       const bf16_t* __restrict__ Bt, int ldb, int M, int N, int K,
                                                       int tiles_n, int nwg, int vec_epilogue, GemmEpilogue ep) {
@@ -61,7 +60,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
   constexpr int A_PIECES = BM / 32;               // 1-KiB DMA pieces per wave per K-tile
   constexpr int SROWS = BM < 64 ? BM : 64;        // rows staged per epilogue pass
   constexpr int STAGE_BYTES = SROWS * STAGE_LD * 4;
-  constexpr int SMEM_BYTES = 2 * BUF_BYTES > STAGE_BYTES ? 2 * BUF_BYTES : STAGE_BYTES;
+  constexpr int SMEM_BYTES = NS * BUF_BYTES > STAGE_BYTES ? NS * BUF_BYTES : STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   // ---- XCD-aware bijective remap (block b runs on XCD b % 8; give each XCD a contiguous band)
@@ -121,15 +120,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
   const int nk = K / BK;
-  issue_tile(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) {
-      issue_tile(kt + 1, buf ^ 1);
-      wait_vmcnt<A_PIECES + 4>();        // tile kt landed, tile kt+1 stays in flight
-    } else {
-      wait_vmcnt<0>();
-    }
+  auto compute_tile = [&](int buf) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const unsigned char* tb = smem + buf * BUF_BYTES;
@@ -149,6 +140,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();        // all waves done with buf before it is re-filled / re-used
+  };
+  if constexpr (NS == 2) {
+    issue_tile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) {
+        issue_tile(kt + 1, buf ^ 1);
+        wait_vmcnt<A_PIECES + 4>();        // tile kt landed, tile kt+1 stays in flight
+      } else {
+        wait_vmcnt<0>();
+      }
+      compute_tile(buf);
+    }
+  } else {
+    // NS - 1 tiles in flight.  Past the end the last tile is re-requested into a buffer nobody reads any more,
+    // which keeps the vmcnt arithmetic uniform; the stragglers are drained before the epilogue reuses the LDS.
+#pragma unroll
+    for (int s2 = 0; s2 < NS - 1; ++s2) issue_tile(s2 < nk ? s2 : nk - 1, s2);
+    int rd = 0, wr = NS - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nxt = kt + NS - 1;
+      issue_tile(nxt < nk ? nxt : nk - 1, wr);
+      wait_vmcnt<(NS - 1) * (A_PIECES + 4)>();
+      compute_tile(rd);
+      rd = rd + 1 == NS ? 0 : rd + 1;
+      wr = wr + 1 == NS ? 0 : wr + 1;
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue through LDS: SROWS rows per pass, every lane owns 4 consecutive columns
@@ -181,12 +201,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
   }
 }
 
-template <int BM>
+template <int BM, int NS>
 void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K, int vec, const GemmEpilogue& ep,
                hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL(gemm_nt_kernel<BM>, dim3(nwg), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, vec, ep);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, NS>), dim3(nwg), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, vec, ep);
 }
 
 }  // namespace
@@ -194,7 +214,7 @@ void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N
 // process-wide kernel-selection knobs (smd_set_tuning in the C-ABI)
 namespace {
 struct Knob { const char* key; int value; };
-Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_tn256", 1}};
+Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_tn256", 1}, {"ln_bwd_wide", 1}, {"gemm_nt_deep", 1}};
 }
 int smd_tuning_set(const char* key, int value) {
   for (Knob& k : g_knobs)
@@ -223,10 +243,16 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
   const int tiles_n = (N + BN - 1) / BN;
   const long wg128 = (long)((M + 127) / 128) * tiles_n;
   const long wg64 = (long)((M + 63) / 64) * tiles_n;
-  if (M <= 32) launch_bm<32>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
-  else if (wg128 >= 512) launch_bm<128>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
-  else if (wg64 >= 256 || M <= 64) launch_bm<64>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
-  else launch_bm<32>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  const bool deep = K >= 8 * BK && smd_tuning_get("gemm_nt_deep");
+  if (M <= 32 || !(wg128 >= 512 || wg64 >= 256 || M <= 64)) {
+    if (deep) launch_bm<32, 4>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+    else launch_bm<32, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  } else if (wg128 >= 512) {
+    launch_bm<128, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  } else {
+    if (deep) launch_bm<64, 4>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+    else launch_bm<64, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  }
   SMD_LAUNCH_CHECK();
   return 0;
 }

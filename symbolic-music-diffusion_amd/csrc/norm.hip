@@ -234,6 +234,145 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdDev a) {
   }
 }
 
+// Wide rows (D >= 1024): the register-resident kernel above needs 8 x D/64 values per lane (256 VGPRs at
+// D = 2048: one wave per SIMD, latency-bound at ~1.3 TB/s).  This variant
+//   * keeps only TWO column accumulators per element.  With e = dy * act'(.) (the gradient wrt the FiLM output),
+//     P_c = sum_r e_rc * xhat_rc and Q_c = sum_r e_rc give every column gradient of the row group:
+//        dshift = Q, dscale = gamma*P + beta*Q, dgamma = scale*P, dbeta = scale*Q   (FiLM: scale is per group)
+//        dgamma = P, dbeta = Q                                                        (no FiLM)
+//   * holds gamma/beta/scale/shift in LDS (16 KiB..32 KiB per workgroup) instead of registers,
+// so a wave needs < 256 VGPRs without spilling -> 2 waves per SIMD (twice the rows in flight per CU) and half the
+// accumulate work per element.
+template <int D>
+__global__ __launch_bounds__(256, 2) void layernorm_bwd_wide_kernel(LnBwdDev a) {
+  typedef RowLayout<D> L;
+  constexpr int PL = L::PER_LANE, NV = L::NV;
+  __shared__ __attribute__((aligned(16))) float prm[4][D];      // gamma, beta, scale, shift; later the combine buffer
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int grp = blockIdx.x;
+  const int r_begin = grp * a.group_rows;
+  int r_end = r_begin + a.group_rows;
+  r_end = r_end < a.f.rows ? r_end : a.f.rows;
+  const bool film = a.f.film_scale != nullptr;
+  const bool swish = a.f.swish != 0;
+  {
+    const int frow = film ? (a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample) : 0;
+    const float* src[4] = {a.f.gamma, a.f.beta, film ? a.f.film_scale + (size_t)frow * a.f.ld_film : nullptr,
+                           film ? a.f.film_shift + (size_t)frow * a.f.ld_film : nullptr};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (src[q])
+        for (int c = threadIdx.x * 4; c < D; c += 1024)
+          *reinterpret_cast<float4*>(&prm[q][c]) = *reinterpret_cast<const float4*>(src[q] + c);
+  }
+  __syncthreads();
+
+  float P[PL], Q[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) P[i] = Q[i] = 0.f;
+
+  for (int row = r_begin + w; row < r_end; row += 4) {
+    float x[PL], dxh[PL];
+    bf16x4_t dyb[NV];
+    load_row<D>(a.f.x, a.f.x_bf16, row, lane, x);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) dyb[k] = *reinterpret_cast<const bf16x4_t*>(a.dout + (size_t)row * D + k * 256 + lane * 4);
+    float mean, rstd;
+    row_stats<D>(x, mean, rstd);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = k * 256 + lane * 4;
+      const float4 g4 = *reinterpret_cast<const float4*>(&prm[0][c]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&prm[1][c]);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      float ss[4] = {1.f, 1.f, 1.f, 1.f}, hh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (film) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&prm[2][c]);
+        const float4 h4 = *reinterpret_cast<const float4*>(&prm[3][c]);
+        ss[0] = s4.x; ss[1] = s4.y; ss[2] = s4.z; ss[3] = s4.w;
+        hh[0] = h4.x; hh[1] = h4.y; hh[2] = h4.z; hh[3] = h4.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = k * 4 + e;
+        const float xh = (x[i] - mean) * rstd;
+        float d = bf2f(dyb[k][e]);
+        if (swish) d *= swish_gradf_(ss[e] * (xh * gg[e] + bb[e]) + hh[e]);     // scale 1 / shift 0 without FiLM
+        Q[i] += d;
+        P[i] += d * xh;
+        const float dh = d * ss[e] * gg[e];
+        x[i] = xh;
+        dxh[i] = dh;
+        s1 += dh;
+        s2 += dh * xh;
+      }
+      __builtin_amdgcn_sched_barrier(0);    // keep the LDS parameter reads of later chunks from being hoisted (VGPRs)
+    }
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < PL; ++i) dxh[i] = rstd * (dxh[i] - s1 - x[i] * s2);
+    if (a.dres) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) {
+        const float4 r = *reinterpret_cast<const float4*>(a.dres + (size_t)row * D + k * 256 + lane * 4);
+        dxh[k * 4 + 0] += r.x; dxh[k * 4 + 1] += r.y; dxh[k * 4 + 2] += r.z; dxh[k * 4 + 3] += r.w;
+      }
+    }
+    if (a.dx_f32) store_row_f32<D>(a.dx_f32, row, lane, dxh);
+    if (a.dx_bf16) store_row_bf16<D>(a.dx_bf16, row, lane, dxh);
+  }
+
+  // ---- combine the 4 waves' P and Q through LDS (fixed order), then expand to the column gradients
+  constexpr int CPT = D / 256;                      // columns per thread: c = threadIdx.x + 256*j
+  float gc[CPT], bc[CPT], sc[CPT], Pc[CPT], Qc[CPT];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    gc[j] = prm[0][c]; bc[j] = prm[1][c]; sc[j] = film ? prm[2][c] : 1.0f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PL; ++i) prm[w][L::col(lane, i)] = P[i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    Pc[j] = (prm[0][c] + prm[1][c]) + (prm[2][c] + prm[3][c]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PL; ++i) prm[w][L::col(lane, i)] = Q[i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    Qc[j] = (prm[0][c] + prm[1][c]) + (prm[2][c] + prm[3][c]);
+  }
+  float* pg = a.partial + ((size_t)grp * 2 + 0) * D;
+  float* pb = a.partial + ((size_t)grp * 2 + 1) * D;
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    pg[c] = sc[j] * Pc[j];
+    pb[c] = sc[j] * Qc[j];
+  }
+  if (film && a.dscale) {
+    const int srow = r_begin / a.f.rows_per_sample;
+    float* ds = a.dscale + (size_t)srow * a.f.ld_film;
+    float* dh = a.dshift + (size_t)srow * a.f.ld_film;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const int c = threadIdx.x + 256 * j;
+      const float vs = gc[j] * Pc[j] + bc[j] * Qc[j], vh = Qc[j];
+      ds[c] = a.dfilm_accumulate ? ds[c] + vs : vs;
+      dh[c] = a.dfilm_accumulate ? dh[c] + vh : vh;
+    }
+  }
+}
+
 // dgamma[c] += sum_g partial[g][0][c] ; dbeta likewise (fixed order -> deterministic)
 // 64 columns x 4 group-slices per block: many independent loads in flight instead of one long
 // dependent chain per column (the one-thread-per-column version was latency-bound at ~65 us).
@@ -302,6 +441,12 @@ template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(layernorm_fwd_kernel<D>, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
 }
 template <int D> static void run_bwd(const LnBwdDev& d, int ngroups, hipStream_t st) {
+  if constexpr (D >= 1024 && D <= 2048) {      // 4096: 64 KiB of LDS parameters, keep the register kernel
+    if (smd_tuning_get("ln_bwd_wide")) {
+      hipLaunchKernelGGL(layernorm_bwd_wide_kernel<D>, dim3(ngroups), dim3(256), 0, st, d);
+      return;
+    }
+  }
   hipLaunchKernelGGL(layernorm_bwd_kernel<D>, dim3(ngroups), dim3(256), 0, st, d);
 }
 

@@ -11,6 +11,8 @@ import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -188,6 +190,9 @@ class Engine:
         self.metrics = torch.zeros(4, dtype=torch.float32, device=self.device)
         _lib.check(self.L.smd_engine_bind_train(self.h, _ptr(self.grads), _ptr(self.m), _ptr(self.v), _ptr(self.ema),
                                                 _ptr(self.step_counter), _ptr(self.metrics)), "bind_train")
+        # weight-gradient GEMMs overlap the dgrad/LayerNorm chain on the engine's low-priority side stream
+        with torch.cuda.device(self.device):
+            self.set_option("side_wgrad", int(os.environ.get("SMD_SIDE_WGRAD", "1")))
 
     # ------------------------------------------------------------------ model(x, cond)
     def forward(self, x: torch.Tensor, noise_level: torch.Tensor) -> torch.Tensor:

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--variants", type=lambda t: [int(x) for x in t.split(",")], default=[0, 1])
     ap.add_argument("--shapes", default="8192x2048x2048")
+    ap.add_argument("--deep-ab", action="store_true", help="A/B of the 2- vs 4-stage skinny NT GEMM")
+    ap.add_argument("--ln-ab", action="store_true", help="interleaved A/B of the LayerNorm backward kernels")
     ap.add_argument("--tn-ab", action="store_true", help="interleaved A/B of the wgrad kernels")
     ap.add_argument("--gemm-ab", action="store_true", help="only the interleaved A/B of the NT GEMM kernels/variants")
     a = ap.parse_args()
@@ -57,6 +59,49 @@ def main():
 
     R = 8192
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+    if a.deep_ab:
+        for (M, N, K) in [(R, 128, 2048), (R, 128, 512), (R, 384, 128), (R, 128, 128), (R, 512, 2048), (256, 4096, 512)]:
+            A, Bt = bf(M, K), bf(N, K)
+            bias = torch.zeros(N, device=dev)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            f = lambda: lib.check(L.smd_gemm_bf16_nt(A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), 0, None, 0,
+                                                     None, 0, out.data_ptr(), N, st))
+            res = {0: [], 1: []}
+            for _ in range(5):
+                for mode in (0, 1):
+                    lib.check(L.smd_set_tuning(b"gemm_nt_deep", mode))
+                    res[mode].append(timeit(f, a.reps))
+            for mode in (0, 1):
+                rec(f"deep_ab:{'4-stage' if mode else '2-stage'}", [M, N, K], sorted(res[mode])[2], flops=2.0 * M * N * K,
+                    bytes_=2.0 * (M * K + N * K + M * N))
+        lib.check(L.smd_set_tuning(b"gemm_nt_deep", 1))
+        return
+    if a.ln_ab:
+        for D, film, xb in ((2048, 0, 0), (2048, 1, 0), (2048, 1, 1), (1024, 1, 0)):
+            x = torch.randn(R, D, device=dev)
+            xbf = x.to(torch.bfloat16)
+            g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+            ss = torch.randn(R // 32, 2 * D, device=dev)
+            dout = bf(R, D)
+            dx = torch.empty(R, D, device=dev)
+            dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+            dss = torch.zeros(R // 32, 2 * D, device=dev)
+            part = torch.empty(R * 2 * D // 16, device=dev)
+            # C-ABI form: fp32 x, fp32 dx out (the engine's ln1 also reads dres and writes bf16: more traffic)
+            f = lambda: lib.check(L.smd_layernorm_bwd(x.data_ptr(), R, D, g.data_ptr(), b.data_ptr(),
+                                                      ss.data_ptr() if film else None, ss[:, D:].data_ptr() if film else None,
+                                                      2 * D, 32, film, dout.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                      dss.data_ptr() if film else None, dss[:, D:].data_ptr() if film else None,
+                                                      part.data_ptr(), part.numel(), st))
+            res = {0: [], 1: []}
+            for _ in range(5):
+                for mode in (0, 1):
+                    lib.check(L.smd_set_tuning(b"ln_bwd_wide", mode))
+                    res[mode].append(timeit(f, a.reps))
+            for mode in (0, 1):
+                rec(f"ln_ab:{'wide' if mode else 'regs'}(film={film}) +reduce", [R, D], sorted(res[mode])[2], bytes_=R * D * 10.0)
+        lib.check(L.smd_set_tuning(b"ln_bwd_wide", 1))
+        return
     if a.tn_ab:
         for (M, Kd, N) in [(R, 2048, 2048), (R, 2048, 512), (4 * R, 2048, 2048)]:
             X, Y = bf(M, Kd), bf(M, N)
