@@ -132,6 +132,12 @@ enum { SMD_EPI_NONE = 0, SMD_EPI_GELU = 1, SMD_EPI_SWISH = 2 };
 int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, int M, int N, int K,
                      const float* bias, int act, const float* residual, int ld_res, float* out_f32, int ld_out,
                      smd_bf16* out_bf16, int ld_outb, void* stream);
+/* Fused encoder MLP half-layer, models/ncsn.py:163-168: h_out = h_in + Dense(gelu(Dense(LN(h_in)))) for the
+ * 128-wide residual stream, rows % 32 == 0.  W1t [hidden][128] and W2t [128][hidden] are bf16 with the contraction
+ * index contiguous; save_* (optional) receive LN output, pre-GELU and post-GELU activations for the backward. */
+int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
+                      const smd_bf16* W1t, const float* b1, const smd_bf16* W2t, const float* b2, int hidden,
+                      smd_bf16* save_a2, smd_bf16* save_z1, smd_bf16* save_u, void* stream);
 /* dW[Kd,N] = X[M,Kd]^T dY[M,N] and db[N] = colsum(dY) (weight + bias gradient of nn.Dense).
  * tr_path 1: zero_page = 128 zeroed bf16, slab = smd_gemm_tn_slab_elems() floats (split-K partials);
  * tr_path 0: scratch = (Kd+N)*roundup(M,64) bf16 for explicit transposes (+ slab for the bias). */

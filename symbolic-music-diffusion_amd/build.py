@@ -14,12 +14,16 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "attention.hip", "diffusion.hip", "optim.hip",
+SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "attention.hip", "encoder_fused.hip", "diffusion.hip", "optim.hip",
            "engine.hip", "capi.hip"]
 HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h",
            os.path.join("..", "..", "include", "smd_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+# per-file code generation switches
+EXTRA_FLAGS = {"encoder_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def find_hipcc() -> str:
@@ -51,7 +55,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         srcp = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_time):
             return obj
-        cmd = [hipcc, *FLAGS, "-c", srcp, "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

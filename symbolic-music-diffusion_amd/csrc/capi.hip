@@ -81,6 +81,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   SMD_ARG_CHECK(key, "set_option: null key");
   if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
   if (std::string(key) == "side_wgrad") return e->impl.set_side_stream(value);
+  if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;
 }
@@ -149,6 +150,12 @@ int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, in
   ep.bias = bias; ep.act = act; ep.res_f32 = residual; ep.ld_res = ld_res;
   ep.out_f32 = out_f32; ep.ld_out = ld_out; ep.out_bf16 = B(out_bf16); ep.ld_outb = ld_outb;
   return launch_gemm_nt(B(A), lda, B(Bt), ldb, M, N, K, ep, S(stream));
+}
+int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta, const smd_bf16* W1t,
+                      const float* b1, const smd_bf16* W2t, const float* b2, int hidden, smd_bf16* save_a2, smd_bf16* save_z1,
+                      smd_bf16* save_u, void* stream) {
+  return launch_mlp_block_fwd(h_in, h_out, rows, gamma, beta, B(W1t), b1, B(W2t), b2, hidden, B(save_a2), B(save_z1), B(save_u),
+                              S(stream));
 }
 int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out, int ldo,
                      float* bias_out, const smd_bf16* zero_page, float* slab, int64_t slab_elems, smd_bf16* scratch,

@@ -1,0 +1,257 @@
+// Fused transformer-encoder half-layers for the 128-wide residual stream (reference models/ncsn.py:159-168):
+//
+//   mlp_block_fwd:   h_out = h_mid + Dense_{2048->128}( gelu( Dense_{128->2048}( LN(h_mid) ) ) )     (:163-168)
+//
+// Why fused: as separate launches the encoder is 16 % of the flops but ~45 % of a denoising step -- every
+// kernel is bound by launch boundaries and by re-streaming 2048-wide activations through HBM.  Here one
+// workgroup owns one sample (S = 32 token rows = exactly one 32-row MFMA tile) and walks the hidden dimension
+// in chunks of 128 units; the 2048-wide hidden activation never leaves the registers:
+//
+//   * LN(h_mid) -> a2 (bf16) goes to LDS once; its MFMA B-fragments (8 k-steps) stay in registers.
+//   * per chunk c, wave w:  z^T[32 hidden x 32 tokens] = W1[c*128 + w*32 .. +32][:] * a2^T   (8 MFMA 32x32x16),
+//     + b1, GELU in the accumulator registers, which then ARE the A-fragments of the second GEMM: the 32x32 C
+//     layout (lane = token column, 16 hidden rows per lane) matches the A layout (lane = token row, 8 k per
+//     k-step) up to a permutation of the contraction index, and the W2 B-fragments are gathered with the same
+//     permutation (two 8-byte LDS reads).  h_part[32 tokens x 128] += u * W2[chunk]  (8 MFMA).
+//   * the four waves contract disjoint hidden slices; their partial h_out tiles are summed through LDS,
+//     + b2 + residual, one fp32 store of the [32 x 128] result.
+//   * weights stream HBM/L2 -> LDS with buffer_load ... lds (64 KiB per chunk: W1 slice + W2 slice), double
+//     buffered, one chunk in flight behind the compute; 256-B LDS rows, 16-B chunk c of row r stored at
+//     c ^ (r & 15) (source-side swizzle) so that the 16-lane ds_read_b128 groups are conflict-free.
+//   * training: a2, z1 (pre-GELU) and u are written out for the backward pass straight from the C layout.
+#include "smd_kernels.h"
+
+namespace {
+
+constexpr int S_TOK = 32, E_DIM = 128, CH = 128;        // tokens per sample, stream width, hidden units per chunk
+constexpr int W_SLICE = CH * E_DIM * 2;                 // 32 KiB: 128 rows x 256 B
+constexpr int BUF_BYTES = 2 * W_SLICE;                  // W1 slice + W2 slice
+constexpr int OFF_A2 = 2 * BUF_BYTES;                   // a2 tile [32][128] bf16 = 8 KiB
+constexpr int MAX_HIDDEN = 8192;
+constexpr int SMEM_BYTES = OFF_A2 + S_TOK * E_DIM * 2;  // 136 KiB
+constexpr float LN_EPS = 1e-6f;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(3))) bf16x8_t* lds_b128_ptr;
+typedef const __attribute__((address_space(3))) bf16x4_t* lds_b64_ptr;
+typedef const __attribute__((address_space(3))) unsigned char* lds_byte_ptr;
+typedef const __attribute__((address_space(3))) float4* lds_f4_ptr;
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+struct MlpArgs {
+  const float* h_in;        // [R][128] fp32 residual stream (h_mid)
+  float* h_out;             // [R][128] (may alias h_in)
+  const float* gamma; const float* beta;
+  const bf16_t* W1t;        // [M][128]  (nn.Dense kernel transposed: hidden-major, contraction contiguous)
+  const float* b1;          // [M]
+  const bf16_t* W2t;        // [128][M]
+  const float* b2;          // [128]
+  int M;                    // hidden width (multiple of 128)
+  bf16_t* save_a2;          // [R][128] or null
+  bf16_t* save_z1;          // [R][M] or null   (pre-activation)
+  bf16_t* save_u;           // [R][M] or null   (gelu output)
+};
+
+union Frag8 {
+  bf16x8_t v;
+  bf16x4_t h[2];
+};
+
+// Built with -mllvm -amdgpu-mfma-vgpr-form (build.py): otherwise hipcc parks the accumulators in AGPRs and copies
+// all 64 of acc_o out and back every chunk.
+template <int V>
+__global__ __launch_bounds__(256) void mlp_block_fwd_kernel(MlpArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t row0 = (size_t)blockIdx.x * S_TOK;
+  const int kh = lane >> 5, l31 = lane & 31;
+
+  // ---- weight DMA: 8 rounds per slice, wave w + round j covers LDS rows j*16 + w*4 .. +4 (16 lanes per 256-B row)
+  const int rl = w * 4 + (lane >> 4);                                    // row within a 16-row round == row & 15
+  const uint32_t cs = (uint32_t)(((lane & 15) ^ rl) * 16);               // swizzled source chunk, bytes
+  const uint32_t w1_v = (uint32_t)rl * 256u + cs;                        // W1t rows are 256 B, slice rows contiguous
+  const uint32_t w2_v = (uint32_t)rl * (uint32_t)(a.M * 2) + cs;         // W2t rows are M*2 B
+  const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1t), 0, a.M * E_DIM * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2t), 0, a.M * E_DIM * 2, 0x00020000);
+  const uint32_t w2_round = (uint32_t)(16 * a.M * 2);
+  unsigned char* lds_w = smem + w * 1024;
+  auto stage_chunk = [&](int c, int buf) {
+    unsigned char* d1 = lds_w + buf * BUF_BYTES;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16(w1_rsrc, w1_v, (uint32_t)(c * W_SLICE + j * 4096), d1 + j * 4096);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16(w2_rsrc, w2_v, (uint32_t)(c * 256) + j * w2_round, d1 + W_SLICE + j * 4096);
+  };
+  const int nchunks = a.M / CH;
+  // fc1 bias of the lane's 16 hidden rows, fetched one chunk ahead and issued BEFORE that chunk's DMA so that the
+  // counted vmcnt wait of the next iteration also covers it (hidden of element e: hb + (e&3) + 8*(e>>2))
+  float4 bnext[4];
+  auto fetch_bias = [&](int c) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bnext[g] = *reinterpret_cast<const float4*>(a.b1 + c * CH + w * 32 + 4 * kh + 8 * g);
+  };
+  fetch_bias(0);
+  stage_chunk(0, 0);
+
+  // ---- LayerNorm of the sample's 32 rows (wave w: rows w*8 .. +8, two elements per lane) -> a2 tile in LDS
+  {
+    const float2 g2 = *reinterpret_cast<const float2*>(a.gamma + lane * 2);
+    const float2 b2v = *reinterpret_cast<const float2*>(a.beta + lane * 2);
+    float2 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 8 + i) * E_DIM + lane * 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = w * 8 + i;
+      float s = x[i].x + x[i].y, s2 = x[i].x * x[i].x + x[i].y * x[i].y;
+      s = wave_sum(s);
+      s2 = wave_sum(s2);
+      const float mean = s * (1.0f / E_DIM);
+      const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      bf16x2_t o;
+      o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
+      o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
+      // element column = 2*lane -> 16-B chunk lane>>2, byte (lane&3)*4 ; swizzle chunk ^ (r & 15)
+      *reinterpret_cast<bf16x2_t*>(smem + OFF_A2 + r * 256 + (((lane >> 2) ^ (r & 15)) << 4) + (lane & 3) * 4) = o;
+      if (a.save_a2) *reinterpret_cast<bf16x2_t*>(a.save_a2 + (row0 + r) * E_DIM + lane * 2) = o;
+    }
+  }
+  __syncthreads();
+
+  // ---- B fragments of a2^T for the 8 k-steps (lane = token l31, k-chunk 2*ks + kh), kept for the whole kernel
+  bf16x8_t a2f[8];
+  {
+    lds_byte_ptr base = (lds_byte_ptr)smem + OFF_A2 + l31 * 256;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) a2f[ks] = *reinterpret_cast<lds_b128_ptr>(base + (((ks * 2 + kh) ^ (l31 & 15)) << 4));
+  }
+
+  f32x16_t acc_o[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_o[t][e] = 0.0f;
+
+  // W1 A-fragment: row = w*32 + l31 of the slice; W2 B-fragment: row n = nt*32 + l31, hidden bytes w*64 + 32*ks2 (+16), +8*kh
+  const int w1_row_off = (w * 32 + l31) * 256;
+  const int sw = l31 & 15;
+
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    float4 bcur[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bcur[g] = bnext[g];
+    if (c + 1 < nchunks) {
+      fetch_bias(c + 1);
+      if constexpr (!(V & 1)) stage_chunk(c + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    lds_byte_ptr s1 = (lds_byte_ptr)smem + buf * BUF_BYTES;
+    lds_byte_ptr s2 = s1 + W_SLICE;
+
+    if constexpr ((V & 2) != 0) { __builtin_amdgcn_s_barrier(); continue; }
+    // z^T tile (rows = hidden, cols = tokens)
+    f32x16_t z, zb;                     // two accumulators: halves the dependent-MFMA chain (one wave per SIMD)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] = zb[e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks += 2) {
+      const bf16x8_t wf0 = *reinterpret_cast<lds_b128_ptr>(s1 + w1_row_off + (((ks * 2 + kh) ^ sw) << 4));
+      const bf16x8_t wf1 = *reinterpret_cast<lds_b128_ptr>(s1 + w1_row_off + ((((ks + 1) * 2 + kh) ^ sw) << 4));
+      z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, a2f[ks], z, 0, 0, 0);
+      zb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, a2f[ks + 1], zb, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) z[e] += zb[e];
+    // bias (per hidden row), save, GELU, save; hidden of element e: hb + (e&3) + 8*(e>>2), hb = c*128 + w*32 + 4*kh
+    const int hb = c * CH + w * 32 + 4 * kh;
+    Frag8 uf[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = bcur[g];
+      float v[4] = {z[4 * g + 0] + bb.x, z[4 * g + 1] + bb.y, z[4 * g + 2] + bb.z, z[4 * g + 3] + bb.w};
+      if (a.save_z1) {
+        bf16x4_t o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = f2bf(v[i]);
+        *reinterpret_cast<bf16x4_t*>(a.save_z1 + (row0 + l31) * a.M + hb + 8 * g) = o;
+      }
+      bf16x4_t o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = f2bf(geluf_(v[i]));
+      if (a.save_u) *reinterpret_cast<bf16x4_t*>(a.save_u + (row0 + l31) * a.M + hb + 8 * g) = o;
+      uf[g >> 1].h[g & 1] = o;           // k-step g>>1, elements (g&1)*4 .. +4  <->  accumulator elements 4g .. 4g+3
+    }
+    // h_part[token][n] += u[token][hidden slice] * W2[hidden slice][n]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = nt * 32 + l31;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int ch = w * 4 + 2 * ks2;                      // 16-B chunk of hidden bytes w*64 + 32*ks2
+        Frag8 bf;
+        bf.h[0] = *reinterpret_cast<lds_b64_ptr>(s2 + n * 256 + ((ch ^ sw) << 4) + 8 * kh);
+        bf.h[1] = *reinterpret_cast<lds_b64_ptr>(s2 + n * 256 + (((ch + 1) ^ sw) << 4) + 8 * kh);
+        acc_o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(uf[ks2].v, bf.v, acc_o[nt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();      // every wave is done with `buf` before the next iteration refills it
+  }
+
+  // ---- sum the four waves' partial tiles through LDS (the weight buffers are free), + b2 + residual
+  float* red = reinterpret_cast<float*>(smem);           // [4][32][128] fp32 = 64 KiB
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int tok = (e & 3) + 8 * (e >> 2) + 4 * kh;
+      red[(w * S_TOK + tok) * E_DIM + nt * 32 + l31] = acc_o[nt][e];
+    }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = (i * 256 + tid) * 4;                 // 4 consecutive columns of one token row
+    const int tok = idx >> 7, col = idx & 127;
+    const float4 p0 = *reinterpret_cast<const float4*>(red + (0 * S_TOK + tok) * E_DIM + col);
+    const float4 p1 = *reinterpret_cast<const float4*>(red + (1 * S_TOK + tok) * E_DIM + col);
+    const float4 p2 = *reinterpret_cast<const float4*>(red + (2 * S_TOK + tok) * E_DIM + col);
+    const float4 p3 = *reinterpret_cast<const float4*>(red + (3 * S_TOK + tok) * E_DIM + col);
+    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + col);
+    const float4 hr = *reinterpret_cast<const float4*>(a.h_in + (row0 + tok) * E_DIM + col);
+    float4 o;
+    o.x = ((p0.x + p1.x) + (p2.x + p3.x)) + bb.x + hr.x;
+    o.y = ((p0.y + p1.y) + (p2.y + p3.y)) + bb.y + hr.y;
+    o.z = ((p0.z + p1.z) + (p2.z + p3.z)) + bb.z + hr.z;
+    o.w = ((p0.w + p1.w) + (p2.w + p3.w)) + bb.w + hr.w;
+    *reinterpret_cast<float4*>(a.h_out + (row0 + tok) * E_DIM + col) = o;
+  }
+}
+
+}  // namespace
+
+int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
+                         const bf16_t* W1t, const float* b1, const bf16_t* W2t, const float* b2, int M, bf16_t* save_a2,
+                         bf16_t* save_z1, bf16_t* save_u, hipStream_t st) {
+  SMD_ARG_CHECK(h_in && h_out && gamma && beta && W1t && b1 && W2t && b2, "mlp_block_fwd: null pointer");
+  SMD_ARG_CHECK(rows > 0 && rows % S_TOK == 0, "mlp_block_fwd: rows=%d must be a multiple of 32", rows);
+  SMD_ARG_CHECK(M >= CH && M % CH == 0 && M <= MAX_HIDDEN, "mlp_block_fwd: hidden width %d must be a multiple of 128 and <= 8192", M);
+  MlpArgs a;
+  a.h_in = h_in; a.h_out = h_out; a.gamma = gamma; a.beta = beta; a.W1t = W1t; a.b1 = b1; a.W2t = W2t; a.b2 = b2; a.M = M;
+  a.save_a2 = save_a2; a.save_z1 = save_z1; a.save_u = save_u;
+  switch (smd_tuning_get("mlp_variant")) {
+    case 1: hipLaunchKernelGGL(mlp_block_fwd_kernel<1>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(mlp_block_fwd_kernel<2>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(mlp_block_fwd_kernel<0>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+  }
+  SMD_LAUNCH_CHECK();
+  return 0;
+}

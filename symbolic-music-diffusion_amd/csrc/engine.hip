@@ -344,13 +344,22 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       RC(launch_attention_fwd(W.qkv[i], W.o[i], B, S, E, d_.num_heads, st));
       { GemmEpilogue ep; ep.res_f32 = h_in; ep.ld_res = E; ep.out_f32 = h_mid; ep.ld_out = E;
         RC(dense_fwd(p.out, W.o[i], E, R, ep, st)); }
-      ln.x = h_mid; ln.gamma = P(p.ln2.g_off); ln.beta = P(p.ln2.b_off); ln.out = W.a2[i];
-      RC(launch_layernorm_fwd(ln, st));
-      { GemmEpilogue ep; ep.act = SMD_ACT_GELU; ep.out_bf16 = W.u[i]; ep.ld_outb = M;
-        if (tr) { ep.pre_bf16 = W.z1[i]; ep.ld_pre = M; }
-        RC(dense_fwd(p.fc1, W.a2[i], E, R, ep, st)); }
-      { GemmEpilogue ep; ep.res_f32 = h_mid; ep.ld_res = E; ep.out_f32 = h_out; ep.ld_out = E;
-        RC(dense_fwd(p.fc2, W.u[i], M, R, ep, st)); }
+      if (fused_encoder && (!tr || fused_encoder == 2) && S == 32 && E == 128 && M % 128 == 0 && p.fc1.Kp == E && p.fc2.Kp == M) {
+        // LN2 + fc1 + GELU + fc2 + residual in one launch; the 2048-wide hidden stays in registers.  Inference
+        // only by default: with the three saved activations the fused kernel is store-bound (8-byte stores
+        // from the MFMA C layout) and no faster than the separate GEMMs (option fused_encoder = 2 forces it).
+        RC(launch_mlp_block_fwd(h_mid, h_out, R, P(p.ln2.g_off), P(p.ln2.b_off), wpack_ + p.fc1.Wt_off, P(p.fc1.b_off),
+                                wpack_ + p.fc2.Wt_off, P(p.fc2.b_off), M, tr ? W.a2[i] : nullptr, tr ? W.z1[i] : nullptr,
+                                tr ? W.u[i] : nullptr, st));
+      } else {
+        ln.x = h_mid; ln.gamma = P(p.ln2.g_off); ln.beta = P(p.ln2.b_off); ln.out = W.a2[i];
+        RC(launch_layernorm_fwd(ln, st));
+        { GemmEpilogue ep; ep.act = SMD_ACT_GELU; ep.out_bf16 = W.u[i]; ep.ld_outb = M;
+          if (tr) { ep.pre_bf16 = W.z1[i]; ep.ld_pre = M; }
+          RC(dense_fwd(p.fc1, W.a2[i], E, R, ep, st)); }
+        { GemmEpilogue ep; ep.res_f32 = h_mid; ep.ld_res = E; ep.out_f32 = h_out; ep.ld_out = E;
+          RC(dense_fwd(p.fc2, W.u[i], M, R, ep, st)); }
+      }
     }
     {  // models/ncsn.py:170-171
       LnArgs ln;

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
         for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.0f;
   Frags f;
 
-  const int nk = K / TK;   // even, >= 2 (checked by the launcher)
+  const int nk = (V & 64) ? 0 : K / TK;   // even, >= 2 (checked by the launcher); V&64: ablation, epilogue only
+  if constexpr ((V & 64) == 0) {
 
   // ---- prologue: K-tile 0 complete in buffer 0, B0 A0 B1 of K-tile 1 in flight; wave row 1 one barrier behind
   STAGE_B(0, 0, 0); STAGE_A(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   KTILE(1, (void)0, (void)0, (void)0, (void)0, (void)0);
   if (wr == 0) SMD_BAR();
   SMD_PIN();
+  }
 #undef KTILE
 #undef STAGE_A
 #undef STAGE_B
@@ -276,6 +278,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     }                                                                                             \
     __builtin_amdgcn_wave_barrier();                                                              \
   } while (0)
+  if constexpr ((V & 32) != 0) {        // ablation: no epilogue (keep the accumulators alive)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(acc[i][j][t]));
+    return;
+  }
   EPI_PASS(0, 0); EPI_PASS(0, 1); EPI_PASS(1, 0); EPI_PASS(1, 1);
 #undef EPI_PASS
 }
@@ -305,6 +316,9 @@ int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M
     case 3: hipLaunchKernelGGL(gemm_nt256_kernel<3>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
     case 4: hipLaunchKernelGGL(gemm_nt256_kernel<4>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
     case 8: hipLaunchKernelGGL(gemm_nt256_kernel<8>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 32: hipLaunchKernelGGL(gemm_nt256_kernel<32>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 64: hipLaunchKernelGGL(gemm_nt256_kernel<64>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 96: hipLaunchKernelGGL(gemm_nt256_kernel<96>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
     case 12: hipLaunchKernelGGL(gemm_nt256_kernel<12>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
     default: hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
   }

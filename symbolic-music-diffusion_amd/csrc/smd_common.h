@@ -48,10 +48,12 @@ __device__ __forceinline__ float tanhf_(float x) {
   float e = __expf(2.0f * x);
   return 1.0f - 2.0f / (e + 1.0f);
 }
+// gelu(x) = 0.5 x (1 + tanh(u)), u = k0 (x + k1 x^3)  ==  x / (1 + exp(-2u)); one exp2 + one rcp:
+// exp(-2u) = exp2(x * (A + B x^2)),  A = -2 k0 log2(e),  B = A k1
 __device__ __forceinline__ float geluf_(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf_(u));
+  const float A = -2.0f * 0.7978845608028654f * 1.4426950408889634f, Bc = A * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(Bc, x * x, A));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float gelu_gradf_(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;

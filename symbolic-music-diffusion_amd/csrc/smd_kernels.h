@@ -120,6 +120,13 @@ int launch_attention_fwd(const bf16_t* qkv, bf16_t* out, int B, int S, int E, in
 int launch_attention_bwd(const bf16_t* qkv, const bf16_t* dout, bf16_t* dqkv, int B, int S, int E,
                          int H, hipStream_t st);
 
+// ------------------------------------------------------------------ fused encoder half-layers (encoder_fused.hip)
+// h_out = h_in + fc2(gelu(fc1(LN(h_in))))  for rows % 32 == 0; W1t [M][128], W2t [128][M] (the forward operand
+// pack); optional saves for the backward pass: a2 = LN output [rows][128], z1 / u = pre / post GELU [rows][M]
+int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
+                         const bf16_t* W1t, const float* b1, const bf16_t* W2t, const float* b2, int M, bf16_t* save_a2,
+                         bf16_t* save_z1, bf16_t* save_u, hipStream_t st);
+
 // ------------------------------------------------------------------ diffusion elementwise (diffusion.hip)
 // sinusoidal noise embedding, reference models/ncsn.py:28-41: s[n] -> bf16 [n][channels]
 int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_out, hipStream_t st);

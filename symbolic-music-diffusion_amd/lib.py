@@ -76,6 +76,8 @@ _SIGS = {
     "smd_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "smd_gemm_bf16_nt": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
+    "smd_mlp_block_fwd": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, c_void,
+                                    c_void, c_void, c_void]),
     "smd_gemm_bf16_tn": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, c_void, c_void, c_i64, c_void, c_i64, C.c_int, c_void]),
     "smd_gemm_tn_slab_elems": (c_i64, []),

@@ -232,6 +232,42 @@ def test_gemm_tn256(L, dev, M, Kd, N, ldx, ldy):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("rows,M", [(32, 128), (96, 256), (8192, 2048)])
+def test_mlp_block_fwd_fused(L, dev, rows, M):
+    """Fused LN + fc1 + GELU + fc2 + residual (encoder_fused.hip) vs fp64 with the kernel's two bf16 roundings
+    (LN output, GELU output) applied in the reference; saved activations; in-place residual stream."""
+    g = torch.Generator().manual_seed(rows + M)
+    h = torch.randn(rows, 128, generator=g) * 1.5 + 0.3
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)
+    W1 = bf(torch.randn(128, M, generator=g) * 0.09)          # kernel (in, out)
+    b1 = 0.1 * torch.randn(M, generator=g)
+    W2 = bf(torch.randn(M, 128, generator=g) * (1.0 / math.sqrt(M)))
+    b2 = 0.1 * torch.randn(128, generator=g)
+    hd = h.double()
+    mu, var = hd.mean(-1, keepdim=True), hd.var(-1, unbiased=False, keepdim=True)
+    a2 = bf(((hd - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()).float())
+    z = a2.double() @ W1.double() + b1.double()
+    u = bf(O.gelu(z).float())
+    ref = hd + u.double() @ W2.double() + b2.double()
+    hD, gD, bD = h.to(dev), gamma.to(dev), beta.to(dev)
+    W1t, W2t = W1.t().contiguous().to(dev), W2.t().contiguous().to(dev)      # [M][128], [128][M]
+    b1D, b2D = b1.to(dev), b2.to(dev)
+    out = torch.full((rows, 128), float("nan"), device=dev)
+    sa = torch.zeros(rows, 128, dtype=torch.bfloat16, device=dev)
+    sz = torch.zeros(rows, M, dtype=torch.bfloat16, device=dev)
+    su = torch.zeros(rows, M, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_mlp_block_fwd(P(hD), P(out), rows, P(gD), P(bD), P(W1t), P(b1D), P(W2t), P(b2D), M, P(sa), P(sz), P(su), st()))
+    inpl = hD.clone()
+    ck(L, L.smd_mlp_block_fwd(P(inpl), P(inpl), rows, P(gD), P(bD), P(W1t), P(b1D), P(W2t), P(b2D), M, None, None, None, st()))
+    torch.cuda.synchronize()
+    e_out = rel(out.double().cpu() - hd, ref - hd)
+    e_a2, e_z, e_u = rel(sa.float(), a2.float()), rel(sz.float(), z), rel(su.float(), u.float())
+    print(f"mlp_block_fwd rows={rows} M={M}: delta rel {e_out:.2e} a2 {e_a2:.2e} z1 {e_z:.2e} u {e_u:.2e}")
+    assert e_out < 3e-3        # bf16 flips of a2/u at rounding boundaries + fast-math gelu
+    assert e_a2 < 2e-3 and e_z < 4e-3 and e_u < 4e-3
+    assert torch.equal(inpl, out)
+
+
 @pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),
                                           (512, True, True), (1024, True, False)])
 def test_layernorm_fwd_bwd(L, dev, D, film, swish):

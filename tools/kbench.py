@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--json", default="")
     ap.add_argument("--variants", type=lambda t: [int(x) for x in t.split(",")], default=[0, 1])
     ap.add_argument("--shapes", default="8192x2048x2048")
+    ap.add_argument("--mlp", action="store_true", help="fused encoder MLP half-layer")
     ap.add_argument("--deep-ab", action="store_true", help="A/B of the 2- vs 4-stage skinny NT GEMM")
     ap.add_argument("--ln-ab", action="store_true", help="interleaved A/B of the LayerNorm backward kernels")
     ap.add_argument("--tn-ab", action="store_true", help="interleaved A/B of the wgrad kernels")
@@ -59,6 +60,24 @@ def main():
 
     R = 8192
     bf = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+    if a.mlp:
+        M = 2048
+        h = torch.randn(R, 128, device=dev)
+        g, b = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+        W1t, W2t = bf(M, 128), bf(128, M)
+        b1, b2 = torch.zeros(M, device=dev), torch.zeros(128, device=dev)
+        out = torch.empty(R, 128, device=dev)
+        sa = torch.empty(R, 128, dtype=torch.bfloat16, device=dev)
+        sz, su = torch.empty(R, M, dtype=torch.bfloat16, device=dev), torch.empty(R, M, dtype=torch.bfloat16, device=dev)
+        for save, var in ((0, 0), (1, 0), (0, 1), (0, 2)):
+            lib.check(L.smd_set_tuning(b"mlp_variant", var))
+            f = lambda: lib.check(L.smd_mlp_block_fwd(h.data_ptr(), out.data_ptr(), R, g.data_ptr(), b.data_ptr(), W1t.data_ptr(),
+                                                      b1.data_ptr(), W2t.data_ptr(), b2.data_ptr(), M,
+                                                      sa.data_ptr() if save else None, sz.data_ptr() if save else None,
+                                                      su.data_ptr() if save else None, st))
+            rec(f"mlp_block_fwd(save={save},ablate={var})", [R, 128, M], timeit(f, a.reps), flops=4.0 * R * 128 * M)
+        lib.check(L.smd_set_tuning(b"mlp_variant", 0))
+        return
     if a.deep_ab:
         for (M, N, K) in [(R, 128, 2048), (R, 128, 512), (R, 384, 128), (R, 128, 128), (R, 512, 2048), (256, 4096, 512)]:
             A, Bt = bf(M, K), bf(N, K)
