@@ -138,6 +138,12 @@ int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, in
 int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
                       const smd_bf16* W1t, const float* b1, const smd_bf16* W2t, const float* b2, int hidden,
                       smd_bf16* save_a2, smd_bf16* save_z1, smd_bf16* save_u, void* stream);
+/* Fused encoder attention half-layer, models/ncsn.py:159-162: h_out = h_in + out(softmax(q k^T / sqrt(d)) v) with
+ * q,k,v = Dense(LN(h_in)); 32 tokens per sample, 128-wide stream, num_heads in {4, 8, 16}.  Wqkv_t [384][128]
+ * (q | k | v rows), Wo_t [128][128], bf16, contraction contiguous; save_qkv receives the unscaled q. */
+int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
+                       const smd_bf16* Wqkv_t, const float* b_qkv, const smd_bf16* Wo_t, const float* b_o, int num_heads,
+                       smd_bf16* save_a1, smd_bf16* save_qkv, smd_bf16* save_o, void* stream);
 /* dW[Kd,N] = X[M,Kd]^T dY[M,N] and db[N] = colsum(dY) (weight + bias gradient of nn.Dense).
  * tr_path 1: zero_page = 128 zeroed bf16, slab = smd_gemm_tn_slab_elems() floats (split-K partials);
  * tr_path 0: scratch = (Kd+N)*roundup(M,64) bf16 for explicit transposes (+ slab for the bias). */

@@ -157,6 +157,12 @@ int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* ga
   return launch_mlp_block_fwd(h_in, h_out, rows, gamma, beta, B(W1t), b1, B(W2t), b2, hidden, B(save_a2), B(save_z1), B(save_u),
                               S(stream));
 }
+int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta, const smd_bf16* Wqkv_t,
+                       const float* b_qkv, const smd_bf16* Wo_t, const float* b_o, int num_heads, smd_bf16* save_a1,
+                       smd_bf16* save_qkv, smd_bf16* save_o, void* stream) {
+  return launch_attn_block_fwd(h_in, h_out, rows, gamma, beta, B(Wqkv_t), b_qkv, B(Wo_t), b_o, num_heads, B(save_a1), B(save_qkv),
+                               B(save_o), S(stream));
+}
 int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out, int ldo,
                      float* bias_out, const smd_bf16* zero_page, float* slab, int64_t slab_elems, smd_bf16* scratch,
                      int64_t scratch_elems, int tr_path, void* stream) {

@@ -236,6 +236,254 @@ __global__ __launch_bounds__(256) void mlp_block_fwd_kernel(MlpArgs a) {
   }
 }
 
+
+// =====================================================================================================
+//   attn_block_fwd:  h_mid = h_in + out_proj( softmax(q k^T / sqrt(d)) v ),  q,k,v = Dense(LN(h_in))     (:159-162)
+//
+// One workgroup per sample, wave w owns the 32 features [32w, 32w+32) of q, k and v, i.e. whole heads:
+//   * Wqkv (96 KiB) is DMA'd once; LN(h_in) -> a1 tile; its fragments serve as A and as B operand.
+//   * q^T, k^T tiles (features x tokens) = W * a1^T, v tile (tokens x features) = a1 * Wv^T: the C layouts give
+//     8-byte LDS writes of row-major q/k [token][feature] and of v^T [feature][token].
+//   * per head: s^T = k_h q_h^T (one MFMA, lane = query column, 16 keys per lane), softmax over the lane's keys
+//     + one xor-32 shuffle, p (bf16) straight from the accumulator registers as the B fragments of
+//     o_h^T = v_h^T p^T (A fragment gathered from v^T with the matching key permutation).
+//   * Wo is DMA'd into the (now free) Wq region behind the attention; o tile -> out_proj^T -> + bias + residual.
+// =====================================================================================================
+constexpr int AT_W = 0;                                   // Wqkv [384][256 B] (later Wo in the first 32 KiB)
+constexpr int AT_A1 = 384 * 256;                          // a1, later o: [32][256 B]
+constexpr int AT_Q = AT_A1 + 8192;                        // q (scaled) [32][256 B]
+constexpr int AT_K = AT_Q + 8192;                         // k [32][256 B]
+constexpr int VT_LD = 72;                                 // v^T row: 32 keys bf16 + 8 B pad (conflict-free b64 gathers)
+constexpr int AT_VT = AT_K + 8192;                        // v^T [128][72 B]
+constexpr int AT_SMEM = AT_VT + 128 * VT_LD;
+
+struct AttnArgs {
+  const float* h_in; float* h_out;
+  const float* gamma; const float* beta;
+  const bf16_t* Wqkv_t;     // [384][128]
+  const float* b_qkv;       // [384]
+  const bf16_t* Wo_t;       // [128][128]
+  const float* b_o;         // [128]
+  bf16_t* save_a1;          // [R][128] or null
+  bf16_t* save_qkv;         // [R][384] or null (q unscaled, as the unfused path stores it)
+  bf16_t* save_o;           // [R][128] or null
+};
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[AT_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t row0 = (size_t)blockIdx.x * S_TOK;
+  const int kh = lane >> 5, l31 = lane & 31, sw = l31 & 15;
+  lds_byte_ptr L = (lds_byte_ptr)smem;
+
+  // ---- Wqkv DMA: 24 rounds of 16 rows (contiguous 4 KiB each), source-side swizzle as in the MLP kernel
+  const int rl = w * 4 + (lane >> 4);
+  const uint32_t wv = (uint32_t)rl * 256u + (uint32_t)(((lane & 15) ^ rl) * 16);
+  const __amdgpu_buffer_rsrc_t wq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wqkv_t), 0, 384 * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wo_t), 0, 128 * 256, 0x00020000);
+  unsigned char* lds_w = smem + w * 1024;
+#pragma unroll
+  for (int j = 0; j < 24; ++j) glds16(wq_rsrc, wv, (uint32_t)(j * 4096), lds_w + AT_W + j * 4096);
+
+  // ---- LayerNorm -> a1 tile
+  {
+    const float2 g2 = *reinterpret_cast<const float2*>(a.gamma + lane * 2);
+    const float2 b2v = *reinterpret_cast<const float2*>(a.beta + lane * 2);
+    float2 x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 8 + i) * E_DIM + lane * 2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = w * 8 + i;
+      float s = x[i].x + x[i].y, s2 = x[i].x * x[i].x + x[i].y * x[i].y;
+      s = wave_sum(s);
+      s2 = wave_sum(s2);
+      const float mean = s * (1.0f / E_DIM);
+      const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      bf16x2_t o;
+      o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
+      o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
+      *reinterpret_cast<bf16x2_t*>(smem + AT_A1 + r * 256 + (((lane >> 2) ^ (r & 15)) << 4) + (lane & 3) * 4) = o;
+      if (a.save_a1) *reinterpret_cast<bf16x2_t*>(a.save_a1 + (row0 + r) * E_DIM + lane * 2) = o;
+    }
+  }
+  // biases of this wave's features: q/k rows (per accumulator row), v column (per lane)
+  float4 bq[4], bk[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bq[g] = *reinterpret_cast<const float4*>(a.b_qkv + w * 32 + 4 * kh + 8 * g);
+    bk[g] = *reinterpret_cast<const float4*>(a.b_qkv + 128 + w * 32 + 4 * kh + 8 * g);
+  }
+  const float bv = a.b_qkv[256 + w * 32 + l31];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // a1 fragments (lane = token, k-chunk 2*ks + kh): B operand of the transposed GEMMs, A operand of the v GEMM
+  bf16x8_t a1f[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) a1f[ks] = *reinterpret_cast<lds_b128_ptr>(L + AT_A1 + l31 * 256 + (((ks * 2 + kh) ^ sw) << 4));
+
+  // ---- q^T, k^T (rows = features, cols = tokens) and v (rows = tokens, cols = features) of this wave's features
+  f32x16_t cq, ck, cv;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) cq[e] = ck[e] = cv[e] = 0.0f;
+  {
+    lds_byte_ptr wrow = L + AT_W + (w * 32 + l31) * 256;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int co = ((ks * 2 + kh) ^ sw) << 4;
+      const bf16x8_t fq = *reinterpret_cast<lds_b128_ptr>(wrow + co);
+      const bf16x8_t fk = *reinterpret_cast<lds_b128_ptr>(wrow + 128 * 256 + co);
+      const bf16x8_t fv = *reinterpret_cast<lds_b128_ptr>(wrow + 256 * 256 + co);
+      cq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, a1f[ks], cq, 0, 0, 0);
+      ck = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, a1f[ks], ck, 0, 0, 0);
+      cv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f[ks], fv, cv, 0, 0, 0);
+    }
+  }
+  __syncthreads();          // every wave is done reading Wqkv and a1: the regions can be reused
+  // Wo -> first 32 KiB of the weight region, behind the attention
+#pragma unroll
+  for (int j = 0; j < 8; ++j) glds16(wo_rsrc, wv, (uint32_t)(j * 4096), lds_w + AT_W + j * 4096);
+
+  // q (scaled), k -> row-major [token = l31][feature]; feature of element e: w*32 + 4*kh + (e&3) + 8*(e>>2)
+  const float qscale = rsqrtf((float)DH);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int f = w * 32 + 4 * kh + 8 * g;                    // 4 consecutive features
+    const float q4[4] = {cq[4 * g + 0] + bq[g].x, cq[4 * g + 1] + bq[g].y, cq[4 * g + 2] + bq[g].z, cq[4 * g + 3] + bq[g].w};
+    const float k4[4] = {ck[4 * g + 0] + bk[g].x, ck[4 * g + 1] + bk[g].y, ck[4 * g + 2] + bk[g].z, ck[4 * g + 3] + bk[g].w};
+    bf16x4_t qs, qu, kk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { qu[i] = f2bf(q4[i]); qs[i] = f2bf(bf2f(qu[i]) * qscale); kk[i] = f2bf(k4[i]); }
+    const int off = l31 * 256 + (((f >> 3) ^ sw) << 4) + (f & 7) * 2;
+    *reinterpret_cast<bf16x4_t*>(smem + AT_Q + off) = qs;
+    *reinterpret_cast<bf16x4_t*>(smem + AT_K + off) = kk;
+    if (a.save_qkv) {
+      *reinterpret_cast<bf16x4_t*>(a.save_qkv + (row0 + l31) * 384 + f) = qu;
+      *reinterpret_cast<bf16x4_t*>(a.save_qkv + (row0 + l31) * 384 + 128 + f) = kk;
+    }
+  }
+  // v^T [feature = w*32 + l31][token]; tokens of element e: 4*kh + (e&3) + 8*(e>>2)
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4_t vv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vv[i] = f2bf(cv[4 * g + i] + bv);
+    *reinterpret_cast<bf16x4_t*>(smem + AT_VT + (w * 32 + l31) * VT_LD + (4 * kh + 8 * g) * 2) = vv;
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-local LDS round trip (own features only)
+
+  // ---- attention for the heads inside this wave's 32 features
+  constexpr int HPW = 32 / DH;                                 // heads per wave
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int f0 = w * 32 + hh * DH;                           // first feature of the head
+    f32x16_t st;                                               // s^T: rows = keys, cols = queries
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < (DH + 15) / 16; ++ks) {
+      bf16x8_t fk, fq;
+      const int f = f0 + ks * 16 + kh * 8;                     // 8 consecutive features of this lane half
+      if (DH >= 16 || kh == 0) {
+        const int off = l31 * 256 + (((f >> 3) ^ sw) << 4);
+        fk = *reinterpret_cast<lds_b128_ptr>(L + AT_K + off);
+        fq = *reinterpret_cast<lds_b128_ptr>(L + AT_Q + off);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fk[i] = (bf16_t)0.0f; fq[i] = (bf16_t)0.0f; }
+      }
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk, fq, st, 0, 0, 0);
+    }
+    // softmax over keys: 16 in the lane + the other lane half
+    float mx = st[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) mx = fmaxf(mx, st[e]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - mx); sum += st[e]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    Frag8 pf[2];                                               // B fragments of p^T: k-step ks2, element s <-> accumulator element 8*ks2 + s
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pf[e >> 3].v[e & 7] = f2bf(st[e] * inv);
+    // o_h^T [d][query] = v_h^T [d][keys] p^T ; A row i = feature f0 + (l31 % DH), keys of element s at k-step ks2:
+    // 16*ks2 + 4*kh + (s&3) + 8*(s>>2)
+    f32x16_t ot;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ot[e] = 0.0f;
+    lds_byte_ptr vrow = L + AT_VT + (f0 + (l31 % DH)) * VT_LD;
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ++ks2) {
+      Frag8 fv;
+      fv.h[0] = *reinterpret_cast<lds_b64_ptr>(vrow + (16 * ks2 + 4 * kh) * 2);
+      fv.h[1] = *reinterpret_cast<lds_b64_ptr>(vrow + (16 * ks2 + 4 * kh + 8) * 2);
+      ot = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv.v, pf[ks2].v, ot, 0, 0, 0);
+    }
+    // rows i = (e&3) + 8*(e>>2) + 4*kh < DH are features f0 + i of token l31
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i0 = 8 * g + 4 * kh;
+      if (i0 < DH) {
+        bf16x4_t ov;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ov[i] = f2bf(ot[4 * g + i]);
+        const int f = f0 + i0;
+        *reinterpret_cast<bf16x4_t*>(smem + AT_A1 + l31 * 256 + (((f >> 3) ^ sw) << 4) + (f & 7) * 2) = ov;
+        if (a.save_o) *reinterpret_cast<bf16x4_t*>(a.save_o + (row0 + l31) * E_DIM + f) = ov;
+      }
+    }
+  }
+  if (a.save_qkv) {      // v, row-major, from the wave's own v^T rows: thread -> (token l31, 4 features) x 4
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = w * 32 + 4 * kh + 8 * g;
+      bf16x4_t vv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vv[i] = *reinterpret_cast<const bf16_t*>(smem + AT_VT + (f + i) * VT_LD + l31 * 2);
+      *reinterpret_cast<bf16x4_t*>(a.save_qkv + (row0 + l31) * 384 + 256 + f) = vv;
+    }
+  }
+  // residual + bias for the output rows of this lane (features w*32 + 4*kh + 8*g .. +3 of token l31)
+  float4 res[4], bo[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    res[g] = *reinterpret_cast<const float4*>(a.h_in + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g);
+    bo[g] = *reinterpret_cast<const float4*>(a.b_o + w * 32 + 4 * kh + 8 * g);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // Wo landed (and the loads above)
+  __syncthreads();                                             // o tile complete, Wo visible to every wave
+
+  // ---- out_proj^T: rows = output features (wave w: 32 of them), cols = tokens
+  f32x16_t co;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) co[e] = 0.0f;
+  {
+    lds_byte_ptr wrow = L + AT_W + (w * 32 + l31) * 256;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int cof = ((ks * 2 + kh) ^ sw) << 4;
+      const bf16x8_t fw = *reinterpret_cast<lds_b128_ptr>(wrow + cof);
+      const bf16x8_t fo = *reinterpret_cast<lds_b128_ptr>(L + AT_A1 + l31 * 256 + cof);
+      co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fo, co, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 o;
+    o.x = co[4 * g + 0] + bo[g].x + res[g].x;
+    o.y = co[4 * g + 1] + bo[g].y + res[g].y;
+    o.z = co[4 * g + 2] + bo[g].z + res[g].z;
+    o.w = co[4 * g + 3] + bo[g].w + res[g].w;
+    *reinterpret_cast<float4*>(a.h_out + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g) = o;
+  }
+}
+
 }  // namespace
 
 int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
@@ -251,6 +499,25 @@ int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float*
     case 1: hipLaunchKernelGGL(mlp_block_fwd_kernel<1>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL(mlp_block_fwd_kernel<2>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL(mlp_block_fwd_kernel<0>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+  }
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
+                          const bf16_t* Wqkv_t, const float* b_qkv, const bf16_t* Wo_t, const float* b_o, int num_heads,
+                          bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st) {
+  SMD_ARG_CHECK(h_in && h_out && gamma && beta && Wqkv_t && b_qkv && Wo_t && b_o, "attn_block_fwd: null pointer");
+  SMD_ARG_CHECK(rows > 0 && rows % S_TOK == 0, "attn_block_fwd: rows=%d must be a multiple of 32", rows);
+  AttnArgs a;
+  a.h_in = h_in; a.h_out = h_out; a.gamma = gamma; a.beta = beta; a.Wqkv_t = Wqkv_t; a.b_qkv = b_qkv; a.Wo_t = Wo_t; a.b_o = b_o;
+  a.save_a1 = save_a1; a.save_qkv = save_qkv; a.save_o = save_o;
+  const dim3 grid(rows / S_TOK), block(256);
+  switch (num_heads) {
+    case 4: hipLaunchKernelGGL(attn_block_fwd_kernel<32>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(attn_block_fwd_kernel<16>, grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL(attn_block_fwd_kernel<8>, grid, block, 0, st, a); break;
+    default: smd_set_error("attn_block_fwd: num_heads=%d unsupported (4, 8, 16)", num_heads); return -1;
   }
   SMD_LAUNCH_CHECK();
   return 0;

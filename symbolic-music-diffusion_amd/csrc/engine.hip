@@ -338,12 +338,20 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       float* h_out = tr ? (l + 1 < d_.num_layers ? W.h[l + 1] : W.h_last) : W.h[0];
       const EncLayerP& p = enc_[l];
       LnArgs ln;
-      ln.x = h_in; ln.rows = R; ln.D = E; ln.gamma = P(p.ln1.g_off); ln.beta = P(p.ln1.b_off); ln.out = W.a1[i];
-      RC(launch_layernorm_fwd(ln, st));
-      { GemmEpilogue ep; ep.out_bf16 = W.qkv[i]; ep.ld_outb = 3 * E; RC(dense_fwd(p.qkv, W.a1[i], E, R, ep, st)); }
-      RC(launch_attention_fwd(W.qkv[i], W.o[i], B, S, E, d_.num_heads, st));
-      { GemmEpilogue ep; ep.res_f32 = h_in; ep.ld_res = E; ep.out_f32 = h_mid; ep.ld_out = E;
-        RC(dense_fwd(p.out, W.o[i], E, R, ep, st)); }
+      ln.rows = R; ln.D = E;
+      if (fused_encoder && S == 32 && E == 128 && p.qkv.Kp == E && p.out.Kp == E) {
+        // LN1 + QKV + softmax(q k^T) v + out_proj + residual in one launch (saved activations are small: also training)
+        RC(launch_attn_block_fwd(h_in, h_mid, R, P(p.ln1.g_off), P(p.ln1.b_off), wpack_ + p.qkv.Wt_off, P(p.qkv.b_off),
+                                 wpack_ + p.out.Wt_off, P(p.out.b_off), d_.num_heads, tr ? W.a1[i] : nullptr,
+                                 tr ? W.qkv[i] : nullptr, tr ? W.o[i] : nullptr, st));
+      } else {
+        ln.x = h_in; ln.gamma = P(p.ln1.g_off); ln.beta = P(p.ln1.b_off); ln.out = W.a1[i];
+        RC(launch_layernorm_fwd(ln, st));
+        { GemmEpilogue ep; ep.out_bf16 = W.qkv[i]; ep.ld_outb = 3 * E; RC(dense_fwd(p.qkv, W.a1[i], E, R, ep, st)); }
+        RC(launch_attention_fwd(W.qkv[i], W.o[i], B, S, E, d_.num_heads, st));
+        { GemmEpilogue ep; ep.res_f32 = h_in; ep.ld_res = E; ep.out_f32 = h_mid; ep.ld_out = E;
+          RC(dense_fwd(p.out, W.o[i], E, R, ep, st)); }
+      }
       if (fused_encoder && (!tr || fused_encoder == 2) && S == 32 && E == 128 && M % 128 == 0 && p.fc1.Kp == E && p.fc2.Kp == M) {
         // LN2 + fc1 + GELU + fc2 + residual in one launch; the 2048-wide hidden stays in registers.  Inference
         // only by default: with the three saved activations the fused kernel is store-bound (8-byte stores

@@ -127,6 +127,12 @@ int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float*
                          const bf16_t* W1t, const float* b1, const bf16_t* W2t, const float* b2, int M, bf16_t* save_a2,
                          bf16_t* save_z1, bf16_t* save_u, hipStream_t st);
 
+// h_out = h_in + out_proj(attention(qkv(LN(h_in)))), S = 32 tokens per sample, E = 128; Wqkv_t [384][128]
+// (q | k | v rows, head h = rows h*d..), Wo_t [128][128]; optional saves: a1 = LN output, qkv (q unscaled), o
+int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
+                          const bf16_t* Wqkv_t, const float* b_qkv, const bf16_t* Wo_t, const float* b_o, int num_heads,
+                          bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st);
+
 // ------------------------------------------------------------------ diffusion elementwise (diffusion.hip)
 // sinusoidal noise embedding, reference models/ncsn.py:28-41: s[n] -> bf16 [n][channels]
 int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_out, hipStream_t st);

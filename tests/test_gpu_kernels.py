@@ -268,6 +268,47 @@ def test_mlp_block_fwd_fused(L, dev, rows, M):
     assert torch.equal(inpl, out)
 
 
+@pytest.mark.parametrize("rows,H", [(32, 8), (96, 16), (64, 4), (8192, 8)])
+def test_attn_block_fwd_fused(L, dev, rows, H):
+    """Fused LN + QKV + attention + out_proj + residual (encoder_fused.hip) vs the fp64 oracle attention with the
+    kernel's bf16 roundings of the LN output, q/k/v and o applied in the reference."""
+    g = torch.Generator().manual_seed(rows + H)
+    E, d = 128, 128 // H
+    h = torch.randn(rows, E, generator=g) * 1.2 - 0.2
+    gamma, beta = 1 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    Wqkv = bf(torch.randn(E, 3 * E, generator=g) * 0.12)        # kernel (in, out), out = [q | k | v], head h at cols h*d..
+    bqkv = 0.1 * torch.randn(3 * E, generator=g)
+    Wo = bf(torch.randn(E, E, generator=g) * 0.09)
+    bo = 0.1 * torch.randn(E, generator=g)
+    hd = h.double()
+    mu, var = hd.mean(-1, keepdim=True), hd.var(-1, unbiased=False, keepdim=True)
+    a1 = bf(((hd - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()).float())
+    qkv = bf((a1.double() @ Wqkv.double() + bqkv.double()).float())
+    B = rows // 32
+    q, k, v = [t.double().view(B, 32, H, d).transpose(1, 2) for t in qkv.split(E, dim=-1)]       # (B, H, 32, d)
+    qs = bf((q / math.sqrt(d)).float()).double()
+    p = torch.softmax(qs @ k.transpose(-1, -2), dim=-1)
+    o = bf((p @ v).transpose(1, 2).reshape(rows, E).float())
+    ref = hd + o.double() @ Wo.double() + bo.double()
+    D = lambda t: t.to(dev)
+    hD, gD, bD, WqD, bqD, WoD, boD = D(h), D(gamma), D(beta), D(Wqkv.t().contiguous()), D(bqkv), D(Wo.t().contiguous()), D(bo)
+    out = torch.full((rows, E), float("nan"), device=dev)
+    sa = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    sq = torch.zeros(rows, 3 * E, dtype=torch.bfloat16, device=dev)
+    so = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_attn_block_fwd(P(hD), P(out), rows, P(gD), P(bD), P(WqD), P(bqD), P(WoD), P(boD), H, P(sa), P(sq), P(so), st()))
+    inpl = hD.clone()
+    ck(L, L.smd_attn_block_fwd(P(inpl), P(inpl), rows, P(gD), P(bD), P(WqD), P(bqD), P(WoD), P(boD), H, None, None, None, st()))
+    torch.cuda.synchronize()
+    e_out = rel(out.double().cpu() - hd, ref - hd)
+    e_a1, e_qkv, e_o = rel(sa.float(), a1.float()), rel(sq.float(), qkv.float()), rel(so.float(), o.float())
+    print(f"attn_block_fwd rows={rows} H={H}: delta rel {e_out:.2e} a1 {e_a1:.2e} qkv {e_qkv:.2e} o {e_o:.2e}")
+    assert e_a1 < 2e-3 and e_qkv < 2e-3
+    assert e_o < 6e-3          # p is rounded to bf16 before the P V product on the matrix cores
+    assert e_out < 6e-3
+    assert torch.equal(inpl, out)
+
+
 @pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),
                                           (512, True, True), (1024, True, False)])
 def test_layernorm_fwd_bwd(L, dev, D, film, swish):
