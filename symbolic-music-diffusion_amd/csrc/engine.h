@@ -120,6 +120,10 @@ class SmdEngine {
                 int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st, bool allow_side = false);
   int wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bool allow_side, hipStream_t st);
   int join_side(hipStream_t st);
+  int ln_bwd(LnBwdArgs& b, hipStream_t st);
+  int flush_ln_reduce(hipStream_t st);
+  std::vector<LnReduceEntry> ln_pending_;
+  size_t ln_slot_off_ = 0;
   float* P(int64_t off) const { return params_ + off; }
   float* G(int64_t off) const { return grads_ + off; }
 

@@ -230,7 +230,10 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
       t.dz1.resize(L);
       for (auto& p : t.dz1) p = c.take<bf16_t>(R * M);
     }
-    t.ln_partial_elems = ln_bwd_partial_elems((int)R, M > E ? M : E) / (S >= 32 ? 32 : 1) + 2 * (size_t)M;
+    {   // one partial slot per LayerNorm backward (their dgamma/dbeta reductions are batched at the end)
+      const size_t groups = S >= 32 ? (R + 31) / 32 : R;
+      t.ln_partial_elems = (size_t)(2 * K + 1) * groups * 2 * M + (size_t)(L > 0 ? 2 * L + 1 : 0) * groups * 2 * E + 2 * (size_t)M;
+    }
     t.ln_partial = c.take<float>(t.ln_partial_elems);
     t.tn_slab_elems = gemm_tn_slab_elems();
     t.tn_slab = c.take<float>(t.tn_slab_elems);
@@ -444,7 +447,29 @@ static LnArgs ln_args(const float* x, const bf16_t* xb, int rows, const LnP& p, 
   return a;
 }
 
+// LayerNorm backward with its own partial slot; the dgamma/dbeta reduction is deferred to flush_ln_reduce()
+int SmdEngine::ln_bwd(LnBwdArgs& b, hipStream_t st) {
+  const int gr = b.f.film_scale ? b.f.rows_per_sample : 32;
+  const size_t need = (size_t)((b.f.rows + gr - 1) / gr) * 2 * b.f.D;
+  SMD_ARG_CHECK(ln_slot_off_ + need <= W.ln_partial_elems, "ln_bwd: partial workspace exhausted");
+  b.partial = W.ln_partial + ln_slot_off_;
+  b.partial_elems = need;
+  ln_slot_off_ += need;
+  ln_pending_.emplace_back();
+  b.deferred = &ln_pending_.back();
+  return launch_layernorm_bwd(b, st);
+}
+int SmdEngine::flush_ln_reduce(hipStream_t st) {
+  if (ln_pending_.empty()) return 0;
+  const int rc = launch_ln_bwd_reduce_batched(ln_pending_.data(), (int)ln_pending_.size(), st);
+  ln_pending_.clear();
+  return rc;
+}
+
 int SmdEngine::backward_head(hipStream_t st) {
+  ln_slot_off_ = 0;
+  ln_pending_.clear();
+  ln_pending_.reserve(64);
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
   const int R = rows(), B = batch_, K = nblocks();
   // out_proj (models/ncsn.py:178): X = ao, dY = dpred
@@ -454,8 +479,7 @@ int SmdEngine::backward_head(hipStream_t st) {
     b.f = ln_args(W.y[K], nullptr, R, ln_o_, params_);
     b.dout = W.dA_M; b.dx = W.dy; b.dx_bf16 = W.dyb[K];
     b.dgamma = G(ln_o_.g_off); b.dbeta = G(ln_o_.b_off);
-    b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
-    RC(launch_layernorm_bwd(b, st));
+    RC(ln_bwd(b, st));
   }
   for (int k = K - 1; k >= 0; --k) {
     const FilmResP& p = blk_[k];
@@ -469,8 +493,7 @@ int SmdEngine::backward_head(hipStream_t st) {
       b.dout = W.dA_M; b.dx_bf16 = W.do1[k];
       b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 0;
-      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
-      RC(launch_layernorm_bwd(b, st));
+      RC(ln_bwd(b, st));
     }
     RC(dense_bwd(p.r1, W.ya1[k], M, W.do1[k], M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
     {
@@ -481,8 +504,7 @@ int SmdEngine::backward_head(hipStream_t st) {
       b.dout = W.dA_M; b.dres = W.dy; b.dx = W.dy; b.dx_bf16 = W.dyb[k];
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 1;
-      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
-      RC(launch_layernorm_bwd(b, st));
+      RC(ln_bwd(b, st));
     }
     // FiLM generator (models/ncsn.py:52-61)
     RC(launch_cast_pad_bf16(W.dss[k], B, 2 * M, W.dss_bf16, 2 * M, st));
@@ -497,8 +519,7 @@ int SmdEngine::backward_head(hipStream_t st) {
     b.f = ln_args(W.h_last, nullptr, R, ln_f_, params_);
     b.dout = W.dA_E; b.dx = W.dh; b.dx_bf16 = W.dhb[2 * d_.num_layers];
     b.dgamma = G(ln_f_.g_off); b.dbeta = G(ln_f_.b_off);
-    b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
-    RC(launch_layernorm_bwd(b, st));
+    RC(ln_bwd(b, st));
   }
   return 0;
 }
@@ -523,8 +544,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.f = ln_args(W.h_mid[l], nullptr, R, p.ln2, params_);
       b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_mid;
       b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
-      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
-      RC(launch_layernorm_bwd(b, st));
+      RC(ln_bwd(b, st));
     }
     RC(dense_bwd(p.out, W.o[l], E, dh_mid, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st, true));
     RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv[l], B, S, E, d_.num_heads, st));
@@ -534,8 +554,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.f = ln_args(W.h[l], nullptr, R, p.ln1, params_);
       b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_out;
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
-      b.partial = W.ln_partial; b.partial_elems = W.ln_partial_elems;
-      RC(launch_layernorm_bwd(b, st));
+      RC(ln_bwd(b, st));
     }
   }
   return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dhb[0], E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
@@ -564,8 +583,12 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     RC(run_network(nullptr, st));
     RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st));
     if (stage != 3) RC(backward_head(st));
+    if (stage == 1) RC(flush_ln_reduce(st));       // output-stage gradients must be final before the DP all-reduce
   }
-  if (stage == 0 || stage == 2) RC(backward_stem(st));
+  if (stage == 0 || stage == 2) {
+    RC(backward_stem(st));
+    RC(flush_ln_reduce(st));                       // one launch for every pending LayerNorm dgamma/dbeta
+  }
   return join_side(st);      // every gradient is complete on `st` when this returns (stage 1: the output stage)
 }
 

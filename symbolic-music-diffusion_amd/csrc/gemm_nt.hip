@@ -250,8 +250,7 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
   } else if (wg128 >= 512) {
     launch_bm<128, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   } else {
-    if (deep) launch_bm<64, 4>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
-    else launch_bm<64, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+    launch_bm<64, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);   // 4 stages = 96 KiB: 1 workgroup per CU instead of 3, slower (A/B)
   }
   SMD_LAUNCH_CHECK();
   return 0;

@@ -404,6 +404,140 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ D = 128 (the encoder's residual-stream norms)
+// A 512-byte row is too small for one wave: 16 lanes own a row (8 columns each), a wave walks 4 rows at once and
+// both of its row quartets are loaded up front; row statistics are 4-step xor-shuffles inside the 16-lane group;
+// the P/Q column accumulators (see the wide kernel) are folded over the row slots with two more shuffles.
+__global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a) {
+  constexpr int D = 128;
+  __shared__ float red[4][2][D];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int sub = lane >> 4, c0 = (lane & 15) * 8;
+  const int grp = blockIdx.x;
+  const int r_begin = grp * a.group_rows;             // group_rows == 32
+  float g[8];
+  {
+    const float4 g0 = *reinterpret_cast<const float4*>(a.f.gamma + c0), g1 = *reinterpret_cast<const float4*>(a.f.gamma + c0 + 4);
+    g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+  }
+  float P[8], Q[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) P[i] = Q[i] = 0.f;
+  float x[2][8], r[2][8];
+  bf16x8_t dyb[2];
+  bool valid[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = r_begin + it * 16 + w * 4 + sub;
+    valid[it] = row < a.f.rows;
+    const size_t off = (size_t)(valid[it] ? row : 0) * D + c0;
+    if (a.f.x) {
+      const float4 t0 = *reinterpret_cast<const float4*>(a.f.x + off), t1 = *reinterpret_cast<const float4*>(a.f.x + off + 4);
+      x[it][0] = t0.x; x[it][1] = t0.y; x[it][2] = t0.z; x[it][3] = t0.w; x[it][4] = t1.x; x[it][5] = t1.y; x[it][6] = t1.z; x[it][7] = t1.w;
+    } else {
+      const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(a.f.x_bf16 + off);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[it][i] = bf2f(t[i]);
+    }
+    dyb[it] = *reinterpret_cast<const bf16x8_t*>(a.dout + off);
+    if (a.dres) {
+      const float4 t0 = *reinterpret_cast<const float4*>(a.dres + off), t1 = *reinterpret_cast<const float4*>(a.dres + off + 4);
+      r[it][0] = t0.x; r[it][1] = t0.y; r[it][2] = t0.z; r[it][3] = t0.w; r[it][4] = t1.x; r[it][5] = t1.y; r[it][6] = t1.z; r[it][7] = t1.w;
+    }
+  }
+  auto sum16 = [](float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+  };
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = r_begin + it * 16 + w * 4 + sub;
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s += x[it][i]; s2 += x[it][i] * x[it][i]; }
+    s = sum16(s); s2 = sum16(s2);
+    const float mean = s * (1.0f / D);
+    const float rstd = rsqrtf(s2 * (1.0f / D) - mean * mean + LN_EPS);
+    float dxh[8], xh[8], t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xh[i] = (x[it][i] - mean) * rstd;
+      const float d = valid[it] ? bf2f(dyb[it][i]) : 0.f;
+      Q[i] += d;
+      P[i] += d * xh[i];
+      dxh[i] = d * g[i];
+      t1 += dxh[i];
+      t2 += dxh[i] * xh[i];
+    }
+    t1 = sum16(t1) * (1.0f / D);
+    t2 = sum16(t2) * (1.0f / D);
+    float dx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dx[i] = rstd * (dxh[i] - t1 - xh[i] * t2) + (a.dres ? r[it][i] : 0.f);
+    if (valid[it]) {
+      const size_t off = (size_t)row * D + c0;
+      if (a.dx_f32) {
+        *reinterpret_cast<float4*>(a.dx_f32 + off) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+        *reinterpret_cast<float4*>(a.dx_f32 + off + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
+      }
+      if (a.dx_bf16) {
+        bf16x8_t o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = f2bf(dx[i]);
+        *reinterpret_cast<bf16x8_t*>(a.dx_bf16 + off) = o;
+      }
+    }
+  }
+  // fold the 4 row slots of the wave (fixed order), then the 4 waves through LDS
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    P[i] += __shfl_xor(P[i], 16, 64); P[i] += __shfl_xor(P[i], 32, 64);
+    Q[i] += __shfl_xor(Q[i], 16, 64); Q[i] += __shfl_xor(Q[i], 32, 64);
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { red[w][0][c0 + i] = P[i]; red[w][1][c0 + i] = Q[i]; }
+  }
+  __syncthreads();
+  {
+    const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+    a.partial[((size_t)grp * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
+// dgamma / dbeta of several LayerNorms in one launch: entry e sums partial_e[g][0|1][c] over its groups in a fixed
+// order (4 group slices per block, combined through LDS) and ACCUMULATES into the gradient buffer.
+__global__ __launch_bounds__(256) void ln_bwd_reduce_batched_kernel(LnReduceTable t) {
+  __shared__ float red[4][64];
+  int e = 0;
+  while (e + 1 < t.n && (int)blockIdx.x >= t.e[e + 1].block_start) ++e;
+  const LnReduceEntry en = t.e[e];
+  const int D = en.D;
+  const int c = ((int)blockIdx.x - en.block_start) * 64 + (threadIdx.x & 63);      // column in [0, 2D)
+  const int slice = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    const int which = c / D, cc = c - which * D;
+    const float* base = en.partial + (size_t)which * D + cc;
+    int gidx = slice;
+    for (; gidx + 12 < en.ngroups; gidx += 16) {
+      s0 += base[(size_t)gidx * 2 * D];
+      s1 += base[(size_t)(gidx + 4) * 2 * D];
+      s2 += base[(size_t)(gidx + 8) * 2 * D];
+      s3 += base[(size_t)(gidx + 12) * 2 * D];
+    }
+    for (; gidx < en.ngroups; gidx += 4) s0 += base[(size_t)gidx * 2 * D];
+  }
+  red[slice][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && c < 2 * D) {
+    const int which = c / D, cc = c - which * D;
+    float* dst = which ? en.dbeta : en.dgamma;
+    const int l = threadIdx.x;
+    dst[cc] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+}
+
 int ln_group_rows(const LnArgs& f) { return f.film_scale ? f.rows_per_sample : 32; }
 
 }  // namespace
@@ -477,10 +611,37 @@ int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
   d.dfilm_accumulate = a.dfilm_accumulate;
   d.partial = a.partial;
   d.group_rows = gr;
-  SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st));
+  if (a.f.D == 128 && !a.f.film_scale && !a.f.swish && gr == 32 && smd_tuning_get("ln_bwd_wide")) {
+    hipLaunchKernelGGL(layernorm_bwd_narrow128_kernel, dim3(ngroups), dim3(256), 0, st, d);
+  } else {
+    SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st));
+  }
   SMD_LAUNCH_CHECK();
+  if (a.deferred) {          // the caller batches the dgamma/dbeta reductions (launch_ln_bwd_reduce_batched)
+    a.deferred->partial = a.partial; a.deferred->ngroups = ngroups; a.deferred->D = a.f.D;
+    a.deferred->dgamma = a.dgamma; a.deferred->dbeta = a.dbeta; a.deferred->block_start = 0;
+    return 0;
+  }
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((2 * a.f.D + 63) / 64), dim3(256), 0, st, a.partial, ngroups,
                      a.f.D, a.dgamma, a.dbeta);
   SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ln_bwd_reduce_batched(const LnReduceEntry* entries, int n, hipStream_t st) {
+  int i = 0;
+  while (i < n) {
+    LnReduceTable t;
+    t.n = 0;
+    int blocks = 0;
+    for (; i < n && t.n < SMD_LN_REDUCE_MAX; ++i) {
+      t.e[t.n] = entries[i];
+      t.e[t.n].block_start = blocks;
+      blocks += (2 * entries[i].D + 63) / 64;
+      ++t.n;
+    }
+    hipLaunchKernelGGL(ln_bwd_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
+    SMD_LAUNCH_CHECK();
+  }
   return 0;
 }

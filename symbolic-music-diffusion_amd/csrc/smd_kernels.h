@@ -97,6 +97,10 @@ int launch_layernorm_fwd(const LnArgs& a, hipStream_t st);
 //   dgamma/dbeta (+=, the flat gradient buffer is zeroed once per step) via per-group partials
 //   in `partial`; dscale/dshift (fp32 [nsamples][ld_film]) = or += per-sample sums over the
 //   sample's rows (the two FiLM uses inside one DenseResBlock share scale/shift).
+// deferred dgamma/dbeta reduction of one LayerNorm backward (filled by launch_layernorm_bwd when requested)
+struct LnReduceEntry { const float* partial; int ngroups; int D; float* dgamma; float* dbeta; int block_start; };
+#define SMD_LN_REDUCE_MAX 24
+struct LnReduceTable { int n; LnReduceEntry e[SMD_LN_REDUCE_MAX]; };
 struct LnBwdArgs {
   LnArgs f;                          // the forward arguments (x, gamma, beta, film, swish); f.out unused
   const bf16_t* dout = nullptr;
@@ -108,11 +112,14 @@ struct LnBwdArgs {
   float* dscale = nullptr;
   float* dshift = nullptr;
   int dfilm_accumulate = 0;
+  LnReduceEntry* deferred = nullptr; // non-null: skip the reduce launch, describe it here (partial must stay intact)
   float* partial = nullptr;          // workspace >= ln_bwd_partial_elems(rows, D)
   size_t partial_elems = 0;
 };
 size_t ln_bwd_partial_elems(int rows, int D);
 int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st);
+// one launch for the dgamma/dbeta (+=) reductions of up to many LayerNorms (24 per kernel launch)
+int launch_ln_bwd_reduce_batched(const LnReduceEntry* entries, int n, hipStream_t st);
 
 // ------------------------------------------------------------------ attention (attention.hip)
 // qkv bf16 [B*S][3E] ([q|k|v], head h at cols h*d..), out bf16 [B*S][E]; S == 32, d in {8,16,32}
