@@ -87,8 +87,11 @@ struct TnArgs {
   const bf16_t* zero_page;
 };
 
+// NS LDS K-tile buffers: 2 (64 KiB, two workgroups per CU) or 4 (128 KiB; three K-tiles in flight -- for the
+// 128-wide weights every workgroup runs few MFMAs per K-tile and a 2-deep pipeline waits on the DMA latency).
+template <int NS>
 __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];
 
   const int tile = blockIdx.x;
   const int tk = tile / a.tiles_n, tn = tile - tk * a.tiles_n;
@@ -158,14 +161,23 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
   for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
 
   const unsigned lds_base = (unsigned)(size_t)(lds_byte_t*)smem;
-  issue_tile(kt_begin, 0);
+  // prologue: NS-1 tiles in flight (past the end the last tile is re-requested into a buffer nobody reads, which
+  // keeps the vmcnt arithmetic uniform; drained before the epilogue reuses the LDS)
+#pragma unroll
+  for (int s2 = 0; s2 < NS - 1; ++s2) issue_tile(kt_begin + s2 < kt_end ? kt_begin + s2 : kt_end - 1, s2);
+  int buf = 0, wbuf = NS - 1;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) {
-      issue_tile(kt + 1, buf ^ 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (NS == 2) {
+      if (kt + 1 < kt_end) {
+        issue_tile(kt + 1, wbuf);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int nxt = kt + NS - 1;
+      issue_tile(nxt < kt_end ? nxt : kt_end - 1, wbuf);
+      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -188,7 +200,11 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
 #undef SMD_TN_KSTEP
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    buf = buf + 1 == NS ? 0 : buf + 1;
+    wbuf = wbuf + 1 == NS ? 0 : wbuf + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant tail requests
+  __builtin_amdgcn_s_barrier();
 
   // ---- destination of this block's partial: final buffers or its split's slab
   float* dst = a.out;
@@ -389,8 +405,12 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     const int total_kt = (t.Mrows + BKM - 1) / BKM;
     const size_t stride = ((size_t)t.Kd * t.N + t.N + 3) / 4 * 4;
     int nsplit = 1;
-    if (tiles < 512 && t.slab && t.ldo == t.N) {      // keep >= 2 workgroups per CU: split the m range
-      nsplit = (512 + tiles - 1) / tiles;
+    // workgroups wanted on the chip (split-K over m): 512 (two per CU); 256 for the 128-wide weights, where the
+    // slab traffic of 32 splits costs more than the second workgroup per CU gains (kbench --tn128)
+    int target = smd_tuning_get("tn128_target_wgs");
+    if (target == 512 && tiles <= 16) target = 256;
+    if (tiles < target && t.slab && t.ldo == t.N) {
+      nsplit = (target + tiles - 1) / tiles;
       if (nsplit > 32) nsplit = 32;
       if (nsplit > total_kt) nsplit = total_kt;
       const size_t cap = t.slab_elems / stride;
@@ -403,7 +423,8 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
     a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t.slab; a.slab_stride = stride;
     a.tiles_n = tiles_n; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t.zero_page;
-    hipLaunchKernelGGL(gemm_tn_128x128_kernel, dim3(tiles, nsplit), dim3(256), 0, st, a);
+    if (per >= 6 && smd_tuning_get("gemm_tn_deep")) hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, a);
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
       const size_t n_w = (size_t)t.Kd * t.N;

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--mlp", action="store_true", help="fused encoder MLP half-layer")
     ap.add_argument("--deep-ab", action="store_true", help="A/B of the 2- vs 4-stage skinny NT GEMM")
     ap.add_argument("--ln-ab", action="store_true", help="interleaved A/B of the LayerNorm backward kernels")
+    ap.add_argument("--tn128", action="store_true", help="split-K sweep of the 128-wide wgrad kernel")
     ap.add_argument("--tn-ab", action="store_true", help="interleaved A/B of the wgrad kernels")
     ap.add_argument("--gemm-ab", action="store_true", help="only the interleaved A/B of the NT GEMM kernels/variants")
     a = ap.parse_args()
@@ -120,6 +121,27 @@ def main():
             for mode in (0, 1):
                 rec(f"ln_ab:{'wide' if mode else 'regs'}(film={film}) +reduce", [R, D], sorted(res[mode])[2], bytes_=R * D * 10.0)
         lib.check(L.smd_set_tuning(b"ln_bwd_wide", 1))
+        return
+    if a.tn128:
+        lib.check(L.smd_set_tuning(b"gemm_tn256", 0))
+        for (M, Kd, N) in [(R, 128, 2048), (R, 2048, 128), (R, 128, 384), (R, 128, 128), (R, 512, 128), (R, 2048, 512)]:
+            X, Y = bf(M, Kd), bf(M, N)
+            out = torch.empty(Kd, N, device=dev)
+            db = torch.empty(N, device=dev)
+            zero = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+            slab = torch.empty(int(L.smd_gemm_tn_slab_elems()), device=dev)
+            scratch = torch.zeros(128, dtype=torch.bfloat16, device=dev)
+            f = lambda: lib.check(L.smd_gemm_bf16_tn(X.data_ptr(), Kd, Y.data_ptr(), N, M, Kd, N, out.data_ptr(), N,
+                                                     db.data_ptr(), zero.data_ptr(), slab.data_ptr(), slab.numel(),
+                                                     scratch.data_ptr(), scratch.numel(), 1, st))
+            for tgt in (128, 256, 512):
+                for deep in (0, 1):
+                    lib.check(L.smd_set_tuning(b"tn128_target_wgs", tgt))
+                    lib.check(L.smd_set_tuning(b"gemm_nt_deep", deep))
+                    rec(f"tn128(target_wgs={tgt},deep={deep}) +reduce", [M, Kd, N], timeit(f, a.reps), flops=2.0 * M * Kd * N)
+        lib.check(L.smd_set_tuning(b"gemm_nt_deep", 1))
+        lib.check(L.smd_set_tuning(b"gemm_tn256", 1))
+        lib.check(L.smd_set_tuning(b"tn128_target_wgs", 512))
         return
     if a.tn_ab:
         for (M, Kd, N) in [(R, 2048, 2048), (R, 2048, 512), (4 * R, 2048, 2048)]:
