@@ -235,9 +235,21 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         tf = 2.0 * R * M * M / (ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of this kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+        # are collected by tools/collect_profiles.sh and committed as profiles/pmc_gemm_nt256.json (corrected as
+        # MI355X_MICROARCH.md prescribes); a profiler cannot wrap the timed run itself.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_gemm_nt256.json")))
+            if pm.get("shape") == [R, M, M]:
+                traffic = pm["traffic_bytes"]
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_nt256_kernel", "shape": [R, M, M], "achieved": round(tf, 1),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-                "avg_launch_ms": round(ms, 5), "traffic": None}
+                "avg_launch_ms": round(ms, 5), "traffic": traffic,
+                "traffic_note": "bytes per launch at L2's memory side from committed rocprofv3 PMC passes "
+                                "(profiles/pmc_gemm_nt256.json); algorithmic bytes = 75.5e6"}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
