@@ -105,6 +105,8 @@ class SmdEngine {
   // dgrad / LayerNorm chain.  Every gradient buffer a side wgrad reads has its own slot (no reuse inside a
   // step); the side stream is joined at the end of loss_backward().  0 = single stream.
   int set_side_stream(int enable);
+  int group_wgrad = 0;                                        // 1: 128-wide weight gradients in grouped launches at the end
+                                                              // of the backward (A/B: -1.6 % -- deferral loses the overlap)
   int fused_encoder = 1;                                      // encoder_fused.hip half-layer kernels (0: separate launches)
   int side_wgrad = 0;
 
@@ -122,6 +124,8 @@ class SmdEngine {
   int join_side(hipStream_t st);
   int ln_bwd(LnBwdArgs& b, hipStream_t st);
   int flush_ln_reduce(hipStream_t st);
+  int flush_grouped_wgrads(hipStream_t st);
+  std::vector<TnLaunch> deferred_wgrads_;
   std::vector<LnReduceEntry> ln_pending_;
   size_t ln_slot_off_ = 0;
   float* P(int64_t off) const { return params_ + off; }

@@ -63,6 +63,13 @@ int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY
   t.out = G(p.w_off); t.ldo = p.N; t.bias_out = G(p.b_off);
   t.zero_page = W.zero_page; t.slab = W.tn_slab; t.slab_elems = W.tn_slab_elems;
   t.scratch = W.tn_scratch; t.scratch_elems = W.tn_scratch_elems; t.tr_path = tr_path;
+  if (allow_side && group_wgrad && tr_path && t.ldo == t.N) {
+    int per = 0;
+    if (gemm_tn256_plan(t, &per) == 0) {       // a 128-wide-kernel problem: launched with its peers at the end
+      deferred_wgrads_.push_back(t);
+      return 0;
+    }
+  }
   if (!(allow_side && side_wgrad && side_ && tr_path)) return launch_gemm_tn(t, st);
   hipEvent_t ev = take_event();
   SMD_ARG_CHECK(ev, "wgrad: cannot create an event");
@@ -72,6 +79,28 @@ int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY
   t.slab = W.tn_slab_side;
   side_pending_ = true;
   return launch_gemm_tn(t, side_);
+}
+
+// The deferred 128-wide weight gradients (every operand is a saved activation or a per-use gradient slot, so
+// they can wait): grouped launches of <= 8 problems + one slab reduce each, on the side stream when enabled.
+int SmdEngine::flush_grouped_wgrads(hipStream_t st) {
+  if (deferred_wgrads_.empty()) return 0;
+  hipStream_t ls = st;
+  float* slab = W.tn_slab;
+  if (side_wgrad && side_) {
+    hipEvent_t ev = take_event();
+    SMD_ARG_CHECK(ev, "flush_grouped_wgrads: cannot create an event");
+    hipError_t e = hipEventRecord(ev, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
+    if (e != hipSuccess) { smd_set_error("flush_grouped_wgrads: event: %s", hipGetErrorString(e)); return (int)e; }
+    ls = side_;
+    slab = W.tn_slab_side;
+    side_pending_ = true;
+  }
+  for (TnLaunch& t : deferred_wgrads_) t.slab = slab;
+  const int rc = launch_gemm_tn_grouped(deferred_wgrads_.data(), (int)deferred_wgrads_.size(), ls);
+  deferred_wgrads_.clear();
+  return rc;
 }
 
 int SmdEngine::join_side(hipStream_t st) {
@@ -467,6 +496,7 @@ int SmdEngine::flush_ln_reduce(hipStream_t st) {
 }
 
 int SmdEngine::backward_head(hipStream_t st) {
+  deferred_wgrads_.clear();
   ln_slot_off_ = 0;
   ln_pending_.clear();
   ln_pending_.reserve(64);
@@ -583,11 +613,15 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     RC(run_network(nullptr, st));
     RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st));
     if (stage != 3) RC(backward_head(st));
-    if (stage == 1) RC(flush_ln_reduce(st));       // output-stage gradients must be final before the DP all-reduce
+    if (stage == 1) {                              // output-stage gradients must be final before the DP all-reduce
+      RC(flush_ln_reduce(st));
+      RC(flush_grouped_wgrads(st));
+    }
   }
   if (stage == 0 || stage == 2) {
     RC(backward_stem(st));
     RC(flush_ln_reduce(st));                       // one launch for every pending LayerNorm dgamma/dbeta
+    RC(flush_grouped_wgrads(st));
   }
   return join_side(st);      // every gradient is complete on `st` when this returns (stage 1: the output stage)
 }

@@ -87,13 +87,26 @@ struct TnArgs {
   const bf16_t* zero_page;
 };
 
+// Several wgrad problems with the same contraction length in one launch (the 128-wide weights of all encoder
+// layers: one problem alone is a few hundred short workgroups; grouped, the K loops are long and the launch,
+// prologue and slab-reduce costs are paid once).  blockIdx.x walks the concatenated tile lists.
+#define SMD_TN_GROUP_MAX 8
+struct TnGroupArgs {
+  int ngroups;
+  int tile_start[SMD_TN_GROUP_MAX + 1];
+  TnArgs p[SMD_TN_GROUP_MAX];
+};
+
 // NS LDS K-tile buffers: 2 (64 KiB, two workgroups per CU) or 4 (128 KiB; three K-tiles in flight -- for the
 // 128-wide weights every workgroup runs few MFMAs per K-tile and a 2-deep pipeline waits on the DMA latency).
 template <int NS>
-__global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
+__global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];
 
-  const int tile = blockIdx.x;
+  int gi = 0;
+  while (gi + 1 < ga.ngroups && (int)blockIdx.x >= ga.tile_start[gi + 1]) ++gi;
+  const TnArgs a = ga.p[gi];
+  const int tile = (int)blockIdx.x - ga.tile_start[gi];
   const int tk = tile / a.tiles_n, tn = tile - tk * a.tiles_n;
   const int kd0 = tk * BT, n0 = tn * BT;
   const int kt_begin = blockIdx.y * a.ktiles_per_split;
@@ -261,13 +274,21 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnArgs a) {
 
 // out[i] = sum_s slab[s][i] (dW then db).  64 float4 columns x 4 slab-slices per block; each thread
 // adds its slabs in a fixed order and the 4 slices are combined in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, size_t stride, int nsplit,
-                                                           size_t n_w, float* __restrict__ out_w, int n_b,
-                                                           float* __restrict__ out_b) {
+struct RedProb { const float* slab; size_t stride; int nsplit; size_t n_w; float* out_w; int n_b; float* out_b; int block_start; };
+struct RedGroupArgs { int n; RedProb p[SMD_TN_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(RedGroupArgs ga) {
   __shared__ float4 red[4][64];
+  int g = 0;
+  while (g + 1 < ga.n && (int)blockIdx.x >= ga.p[g + 1].block_start) ++g;
+  const RedProb pr = ga.p[g];
+  const float* __restrict__ slab = pr.slab;
+  const size_t stride = pr.stride, n_w = pr.n_w;
+  const int nsplit = pr.nsplit, n_b = pr.n_b;
+  float* __restrict__ out_w = pr.out_w;
+  float* __restrict__ out_b = pr.out_b;
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const size_t total = n_w + (out_b ? (size_t)n_b : 0);
-  const size_t i = ((size_t)blockIdx.x * 64 + lane) * 4;
+  const size_t i = ((size_t)((int)blockIdx.x - pr.block_start) * 64 + lane) * 4;
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
   const bool in = i < total;
   const bool vec = in && (i + 3 < total);
@@ -419,18 +440,21 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     }
     const int per = (total_kt + nsplit - 1) / nsplit;
     nsplit = (total_kt + per - 1) / per;
-    TnArgs a;
+    TnGroupArgs ga;
+    ga.ngroups = 1; ga.tile_start[0] = 0; ga.tile_start[1] = tiles;
+    TnArgs& a = ga.p[0];
     a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
     a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t.slab; a.slab_stride = stride;
     a.tiles_n = tiles_n; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t.zero_page;
-    if (per >= 6 && smd_tuning_get("gemm_tn_deep")) hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, a);
+    if (per >= 6 && smd_tuning_get("gemm_tn_deep")) hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
-      const size_t n_w = (size_t)t.Kd * t.N;
-      const size_t total = n_w + (t.bias_out ? t.N : 0);
-      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t.slab,
-                         stride, nsplit, n_w, t.out, t.N, t.bias_out);
+      RedGroupArgs ra;
+      ra.n = 1;
+      ra.p[0] = RedProb{t.slab, stride, nsplit, (size_t)t.Kd * t.N, t.out, t.N, t.bias_out, 0};
+      const size_t total = ra.p[0].n_w + (t.bias_out ? t.N : 0);
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ra);
       SMD_LAUNCH_CHECK();
     }
     return 0;
@@ -454,6 +478,61 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     rc = launch_colsum_bf16(t.dY, t.ldy, t.Mrows, t.N, t.bias_out, t.slab, t.slab_elems, st);
   }
   return rc;
+}
+
+// Grouped launch of the 128-wide kernel: n problems (<= 8 per launch) sharing Mrows, each with ldo == N; one
+// split count for all, slabs carved from the first problem's workspace, one grouped reduce.
+int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st) {
+  int i0 = 0;
+  while (i0 < n) {
+    const int cnt = (n - i0) < SMD_TN_GROUP_MAX ? (n - i0) : SMD_TN_GROUP_MAX;
+    const TnLaunch& t0 = probs[i0];
+    SMD_ARG_CHECK(t0.zero_page && t0.slab && t0.tr_path, "gemm_tn_grouped: needs zero page, slab workspace and tr_path = 1");
+    const int total_kt = (t0.Mrows + BKM - 1) / BKM;
+    TnGroupArgs ga;
+    ga.ngroups = cnt;
+    int tiles = 0;
+    size_t slab_per_split = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const TnLaunch& t = probs[i0 + i];
+      SMD_ARG_CHECK(t.X && t.dY && t.out && t.Mrows == t0.Mrows && t.ldo == t.N && t.ldx % 8 == 0 && t.ldy % 8 == 0,
+                    "gemm_tn_grouped: problem %d incompatible", i0 + i);
+      ga.tile_start[i] = tiles;
+      tiles += ((t.Kd + BT - 1) / BT) * ((t.N + BT - 1) / BT);
+      slab_per_split += ((size_t)t.Kd * t.N + t.N + 3) / 4 * 4;
+    }
+    ga.tile_start[cnt] = tiles;
+    int nsplit = (512 + tiles - 1) / tiles;
+    if (nsplit > 32) nsplit = 32;
+    if (nsplit > total_kt) nsplit = total_kt;
+    if ((size_t)nsplit * slab_per_split > t0.slab_elems) nsplit = (int)(t0.slab_elems / slab_per_split);
+    if (nsplit < 1) nsplit = 1;            // one split writes the gradients directly, no slab needed
+    const int per = (total_kt + nsplit - 1) / nsplit;
+    nsplit = (total_kt + per - 1) / per;
+    RedGroupArgs ra;
+    ra.n = cnt;
+    size_t slab_off = 0;
+    int blocks = 0;
+    for (int i = 0; i < cnt; ++i) {
+      const TnLaunch& t = probs[i0 + i];
+      const size_t stride = ((size_t)t.Kd * t.N + t.N + 3) / 4 * 4;
+      TnArgs& a = ga.p[i];
+      a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
+      a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t0.slab + slab_off; a.slab_stride = stride;
+      a.tiles_n = (t.N + BT - 1) / BT; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t0.zero_page;
+      ra.p[i] = RedProb{a.slab, stride, nsplit, (size_t)t.Kd * t.N, t.out, t.N, t.bias_out, blocks};
+      blocks += (int)(((size_t)t.Kd * t.N + (t.bias_out ? t.N : 0) + 255) / 256);
+      slab_off += (size_t)nsplit * stride;
+    }
+    hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    SMD_LAUNCH_CHECK();
+    if (nsplit > 1) {
+      hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ra);
+      SMD_LAUNCH_CHECK();
+    }
+    i0 += cnt;
+  }
+  return 0;
 }
 
 // ---- debug probe: what does ds_read_b64_tr_b16 return for a linear image with lane address lane*8 ?

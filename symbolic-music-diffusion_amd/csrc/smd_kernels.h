@@ -65,6 +65,8 @@ size_t gemm_tn_slab_elems();
 int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split);
 int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st);
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st);
+// n wgrad problems with the same Mrows (ldo == N each) in grouped launches of the 128-wide kernel + one reduce
+int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st);
 int launch_transpose_bf16(const bf16_t* in, int ld_in, int rows, int cols, bf16_t* out, int ld_out,
                           hipStream_t st);
 // out[n] = sum_m dY[m][n]  (bias gradient), deterministic two-stage reduction via `partial`

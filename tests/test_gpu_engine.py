@@ -74,8 +74,11 @@ def test_forward_batch_invariance_and_determinism():
 
 
 @pytest.mark.parametrize("arch,C,L,H,K,tr", [("TransformerDDPM", 512, 2, 8, 1, 1), ("TransformerDDPM", 512, 2, 8, 1, 0),
-                                              ("TransformerDDPM", 42, 6, 16, 2, 1), ("DenseDDPM", 512, 2, 8, 2, 1)])
+                                              ("TransformerDDPM", 42, 6, 16, 2, 1), ("DenseDDPM", 512, 2, 8, 2, 1),
+                                              ("TransformerDDPM", 512, 2, 8, 1, 3), ("DenseDDPM", 512, 2, 8, 2, 3)])
 def test_loss_and_gradient_parity(arch, C, L, H, K, tr):
+    """tr: 1 LDS-transpose wgrad kernels (default path), 0 explicit-transpose fallback, 3 = 1 + the optional paths
+    (grouped 128-wide wgrads, single stream, unfused encoder forward, fused training MLP)."""
     ocfg, p, model = make(arch, C, L, H, K)
     B = 64 if arch == "DenseDDPM" else 4
     shape = (C,) if arch == "DenseDDPM" else (32, C)
@@ -88,7 +91,11 @@ def test_loss_and_gradient_parity(arch, C, L, H, K, tr):
     loss_ref.mean().backward()
 
     eng = model.train_engine(ema=True)
-    eng.set_option("tr_path", tr)
+    eng.set_option("tr_path", 1 if tr == 3 else tr)
+    if tr == 3:
+        eng.set_option("group_wgrad", 1)
+        eng.set_option("side_wgrad", 0)
+        eng.set_option("fused_encoder", 2 if arch == "TransformerDDPM" else 0)
     eng.set_schedule(BETAS, with_sampler=False)
     eng.bind(B, training=True)
     eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
