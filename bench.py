@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches for the sample step")
     ap.add_argument("--tr-path", type=int, default=1)
+    ap.add_argument("--engine-opt", action="append", default=[], help="extra engine option key=value (A/B runs)")
     ap.add_argument("--group-wgrad", type=int, default=0, help="128-wide wgrads in grouped launches (0: one launch each)")
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
     return ap.parse_args()
@@ -138,6 +139,9 @@ def main():
     opt.engine.set_option("tr_path", a.tr_path)
     opt.engine.set_option("side_wgrad", a.side_wgrad)
     opt.engine.set_option("group_wgrad", a.group_wgrad)
+    for kv in a.engine_opt:
+        k, _, v = kv.partition("=")
+        opt.engine.set_option(k, int(v))
     key = N.PRNGKey(0)
 
     def one_train():

@@ -144,6 +144,10 @@ int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* ga
 int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
                        const smd_bf16* Wqkv_t, const float* b_qkv, const smd_bf16* Wo_t, const float* b_o, int num_heads,
                        smd_bf16* save_a1, smd_bf16* save_qkv, smd_bf16* save_o, void* stream);
+/* Backward of that half-layer between its LayerNorms: dO = dh_mid Wo^T, attention backward (softmax recomputed
+ * from the saved qkv), da1 = dqkv Wqkv^T.  Wo [128 in][128 out], Wqkv [128 in][384 out]: bf16, out index contiguous. */
+int smd_attn_block_bwd(const smd_bf16* dh_mid, const smd_bf16* qkv, const smd_bf16* Wo, const smd_bf16* Wqkv,
+                       smd_bf16* dqkv, smd_bf16* da1, int rows, int num_heads, void* stream);
 /* dW[Kd,N] = X[M,Kd]^T dY[M,N] and db[N] = colsum(dY) (weight + bias gradient of nn.Dense).
  * tr_path 1: zero_page = 128 zeroed bf16, slab = smd_gemm_tn_slab_elems() floats (split-K partials);
  * tr_path 0: scratch = (Kd+N)*roundup(M,64) bf16 for explicit transposes (+ slab for the bias). */

@@ -81,6 +81,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   SMD_ARG_CHECK(key, "set_option: null key");
   if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
   if (std::string(key) == "side_wgrad") return e->impl.set_side_stream(value);
+  if (std::string(key) == "fused_attn_bwd") { e->impl.fused_attn_bwd = value ? 1 : 0; return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   smd_set_error("set_option: unknown key '%s'", key);
@@ -163,6 +164,10 @@ int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* g
                        smd_bf16* save_qkv, smd_bf16* save_o, void* stream) {
   return launch_attn_block_fwd(h_in, h_out, rows, gamma, beta, B(Wqkv_t), b_qkv, B(Wo_t), b_o, num_heads, B(save_a1), B(save_qkv),
                                B(save_o), S(stream));
+}
+int smd_attn_block_bwd(const smd_bf16* dh_mid, const smd_bf16* qkv, const smd_bf16* Wo, const smd_bf16* Wqkv, smd_bf16* dqkv,
+                       smd_bf16* da1, int rows, int num_heads, void* stream) {
+  return launch_attn_block_bwd(B(dh_mid), B(qkv), B(Wo), B(Wqkv), B(dqkv), B(da1), rows, num_heads, S(stream));
 }
 int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out, int ldo,
                      float* bias_out, const smd_bf16* zero_page, float* slab, int64_t slab_elems, smd_bf16* scratch,

@@ -484,6 +484,274 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
   }
 }
 
+
+// =====================================================================================================
+//   attn_block_bwd:  backward of the attention half-layer between the two LayerNorms, one launch per layer:
+//     dO   = dh_mid Wo^T                        (out_proj dgrad)
+//     dqkv = attention backward (softmax recomputed from the saved q, k, v)
+//     da1  = dqkv Wqkv^T                        (qkv dgrad; input of the ln1 backward)
+//   The two weight gradients (X = o, dY = dh_mid and X = a1, dY = dqkv) stay separate GEMMs; dqkv is written out
+//   for the second one.  One workgroup per sample, wave w owns features [32w, 32w+32) of q, k, v and dO.
+//   Per head the score tile is needed in both orientations: s^T (lane = query; softmax statistics and the row
+//   dot product are in-lane + one shuffle) feeds dq^T = k^T ds^T, and s (lane = key; statistics come back through
+//   a 3x32-float LDS table) feeds dk^T = q^T ds and dv^T = do^T p.  All "transposed" A fragments are
+//   ds_read_b64_tr_b16 gathers from the row-major q / k / dO tiles; p, ds go from the accumulators straight into
+//   B fragments (C layout == B layout up to the contraction permutation the tr-reads are issued with).
+// =====================================================================================================
+constexpr int AB_W = 0;                        // Wo [128][256 B] + dh tile first; later Wqkv as 3 x [128][256 B]
+constexpr int AB_DH = 128 * 256;               // dh_mid tile [32][256 B] (inside the future Wqkv region)
+constexpr int AB_QKV = 3 * 128 * 256;          // saved q | k | v tiles, 3 x [32][256 B]
+constexpr int AB_DO = AB_QKV + 3 * 8192;       // dO tile [32][256 B]
+constexpr int AB_DQKV = AB_DO + 8192;          // dq | dk | dv tiles, 3 x [32][256 B]
+constexpr int AB_ST = AB_DQKV + 3 * 8192;      // per wave: max, 1/sum, row-dot of 32 queries (3 x 32 floats)
+constexpr int AB_SMEM = AB_ST + 4 * 3 * 32 * 4;
+
+struct AttnBwdArgs {
+  const bf16_t* dh_mid;     // [R][128] gradient wrt the half-layer output (bf16)
+  const bf16_t* qkv;        // [R][384] saved (q unscaled)
+  const bf16_t* Wo;         // out_proj kernel as W [in 128][out 128] bf16 (dgrad operand pack)
+  const bf16_t* Wqkv;       // qkv kernel as W [in 128][out 384]
+  bf16_t* dqkv;             // [R][384]
+  bf16_t* da1;              // [R][128]
+};
+
+__device__ __forceinline__ bf16x4_t tr_read(unsigned addr) {
+  bf16x4_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[AB_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t row0 = (size_t)blockIdx.x * S_TOK;
+  const int kh = lane >> 5, l31 = lane & 31, sw = l31 & 15;
+  lds_byte_ptr L = (lds_byte_ptr)smem;
+  const unsigned L0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+  // ---- DMA: 256-B-row tiles, 16 rows per round over the 4 waves, source chunk = position ^ (row & 15)
+  const int rl = w * 4 + (lane >> 4);
+  const uint32_t csw = (uint32_t)(((lane & 15) ^ rl) * 16);
+  unsigned char* lds_w = smem + w * 1024;
+  const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wo), 0, 128 * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wqkv), 0, 128 * 768, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dh_mid + row0 * E_DIM), 0, 32 * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t qkv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.qkv + row0 * 384), 0, 32 * 768, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) glds16(wo_rsrc, (uint32_t)rl * 256u + csw, (uint32_t)(j * 4096), lds_w + AB_W + j * 4096);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) glds16(dh_rsrc, (uint32_t)rl * 256u + csw, (uint32_t)(j * 4096), lds_w + AB_DH + j * 4096);
+#pragma unroll
+  for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      glds16(qkv_rsrc, (uint32_t)rl * 768u + csw, (uint32_t)(pp * 256 + j * 16 * 768), lds_w + AB_QKV + pp * 8192 + j * 4096);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- dO^T (rows = in-features of out_proj = this wave's 32, cols = tokens) = Wo[i][:] . dh[token][:]
+  {
+    f32x16_t c0, c1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c0[e] = c1[e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ks += 2) {
+      const int o0 = ((ks * 2 + kh) ^ sw) << 4, o1 = (((ks + 1) * 2 + kh) ^ sw) << 4;
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<lds_b128_ptr>(L + AB_W + (w * 32 + l31) * 256 + o0),
+                                                   *reinterpret_cast<lds_b128_ptr>(L + AB_DH + l31 * 256 + o0), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<lds_b128_ptr>(L + AB_W + (w * 32 + l31) * 256 + o1),
+                                                   *reinterpret_cast<lds_b128_ptr>(L + AB_DH + l31 * 256 + o1), c1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = w * 32 + 4 * kh + 8 * g;
+      bf16x4_t v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = f2bf(c0[4 * g + i] + c1[4 * g + i]);
+      *reinterpret_cast<bf16x4_t*>(smem + AB_DO + l31 * 256 + (((f >> 3) ^ sw) << 4) + (f & 7) * 2) = v;
+    }
+  }
+  __syncthreads();          // Wo and dh are dead: their space becomes the Wqkv tiles, DMA'd behind the attention
+#pragma unroll
+  for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      glds16(wq_rsrc, (uint32_t)rl * 768u + csw, (uint32_t)(pp * 256 + j * 16 * 768), lds_w + AB_W + pp * 32768 + j * 4096);
+
+  // ---- attention backward, heads inside this wave's 32 features
+  const float scale = rsqrtf((float)DH);
+  float* stats = reinterpret_cast<float*>(smem + AB_ST) + w * 96;
+  const int gg = lane >> 4, ig = lane & 15;
+  constexpr int HPW = 32 / DH;
+  constexpr int KS = (DH + 15) / 16;
+#pragma unroll
+  for (int hh = 0; hh < HPW; ++hh) {
+    const int f0 = w * 32 + hh * DH;
+    // row-major fragments (lane = token l31, 8 consecutive features of this lane half), zero past the head
+    bf16x8_t fq[KS], fk[KS], fv[KS], fd[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int f = f0 + ks * 16 + kh * 8;
+      if (DH >= 16 || kh == 0) {
+        const int off = l31 * 256 + (((f >> 3) ^ sw) << 4);
+        fq[ks] = *reinterpret_cast<lds_b128_ptr>(L + AB_QKV + off);
+        fk[ks] = *reinterpret_cast<lds_b128_ptr>(L + AB_QKV + 8192 + off);
+        fv[ks] = *reinterpret_cast<lds_b128_ptr>(L + AB_QKV + 16384 + off);
+        fd[ks] = *reinterpret_cast<lds_b128_ptr>(L + AB_DO + off);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { fq[ks][i] = (bf16_t)0.0f; fk[ks][i] = (bf16_t)0.0f; fv[ks][i] = (bf16_t)0.0f; fd[ks][i] = (bf16_t)0.0f; }
+      }
+    }
+    // ---- orientation T: rows = keys, cols = queries
+    f32x16_t st, dpt;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = dpt[e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[ks], fq[ks], st, 0, 0, 0);
+      dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[ks], fd[ks], dpt, 0, 0, 0);
+    }
+    float mx = st[0] * scale;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] *= scale; mx = fmaxf(mx, st[e]); }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = __expf(st[e] - mx); sum += st[e]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] *= inv; dot += st[e] * dpt[e]; }
+    dot += __shfl_xor(dot, 32, 64);
+    if (kh == 0) { stats[l31] = mx; stats[32 + l31] = inv; stats[64 + l31] = dot; }
+    Frag8 dst_[2];                                 // ds^T as B fragments (k-step ks2, element s <-> accumulator element 8*ks2 + s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dst_[e >> 3].v[e & 7] = f2bf(st[e] * (dpt[e] - dot));
+    // dq^T [d][query] = k^T [d][keys] ds^T : A gathered from the row-major k tile with transposing reads
+    {
+      f32x16_t dq;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dq[e] = 0.0f;
+      const int fcol = f0 + 16 * (gg & 1) + 4 * (ig & 3);      // the 4 features whose address this lane supplies
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int r0 = 16 * ks2 + 4 * kh + (ig >> 2), r1 = r0 + 8;
+        Frag8 fa;
+        fa.h[0] = tr_read(L0 + AB_QKV + 8192 + r0 * 256 + (((fcol >> 3) ^ (r0 & 15)) << 4) + (fcol & 7) * 2);
+        fa.h[1] = tr_read(L0 + AB_QKV + 8192 + r1 * 256 + (((fcol >> 3) ^ (r1 & 15)) << 4) + (fcol & 7) * 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, dst_[ks2].v, dq, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 8 * g + 4 * kh;
+        if (i0 < DH) {
+          const int f = f0 + i0;
+          bf16x4_t v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = f2bf(dq[4 * g + i] * scale);
+          *reinterpret_cast<bf16x4_t*>(smem + AB_DQKV + l31 * 256 + (((f >> 3) ^ sw) << 4) + (f & 7) * 2) = v;
+          *reinterpret_cast<bf16x4_t*>(a.dqkv + (row0 + l31) * 384 + f) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- orientation N: rows = queries, cols = keys
+    f32x16_t sn, dpn;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sn[e] = dpn[e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], fk[ks], sn, 0, 0, 0);
+      dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd[ks], fv[ks], dpn, 0, 0, 0);
+    }
+    Frag8 pn[2], dsn[2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int q0 = 8 * g + 4 * kh;                            // queries of elements 4g .. 4g+3
+      const float4 m4 = *reinterpret_cast<const float4*>(stats + q0);
+      const float4 i4 = *reinterpret_cast<const float4*>(stats + 32 + q0);
+      const float4 d4 = *reinterpret_cast<const float4*>(stats + 64 + q0);
+      const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, ii[4] = {i4.x, i4.y, i4.z, i4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = 4 * g + i;
+        const float pv = __expf(sn[e] * scale - mm[i]) * ii[i];
+        pn[e >> 3].v[e & 7] = f2bf(pv);
+        dsn[e >> 3].v[e & 7] = f2bf(pv * (dpn[e] - dd[i]));
+      }
+    }
+    {
+      f32x16_t dk, dv;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dk[e] = dv[e] = 0.0f;
+      const int fcol = f0 + 16 * (gg & 1) + 4 * (ig & 3);
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        const int r0 = 16 * ks2 + 4 * kh + (ig >> 2), r1 = r0 + 8;
+        const int o0 = r0 * 256 + (((fcol >> 3) ^ (r0 & 15)) << 4) + (fcol & 7) * 2;
+        const int o1 = r1 * 256 + (((fcol >> 3) ^ (r1 & 15)) << 4) + (fcol & 7) * 2;
+        Frag8 fqT, fdT;
+        fqT.h[0] = tr_read(L0 + AB_QKV + o0);
+        fqT.h[1] = tr_read(L0 + AB_QKV + o1);
+        fdT.h[0] = tr_read(L0 + AB_DO + o0);
+        fdT.h[1] = tr_read(L0 + AB_DO + o1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fqT.v, dsn[ks2].v, dk, 0, 0, 0);
+        dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fdT.v, pn[ks2].v, dv, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i0 = 8 * g + 4 * kh;
+        if (i0 < DH) {
+          const int f = f0 + i0;
+          bf16x4_t vk, vv;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { vk[i] = f2bf(dk[4 * g + i] * scale); vv[i] = f2bf(dv[4 * g + i]); }
+          const int off = l31 * 256 + (((f >> 3) ^ sw) << 4) + (f & 7) * 2;
+          *reinterpret_cast<bf16x4_t*>(smem + AB_DQKV + 8192 + off) = vk;
+          *reinterpret_cast<bf16x4_t*>(smem + AB_DQKV + 16384 + off) = vv;
+          *reinterpret_cast<bf16x4_t*>(a.dqkv + (row0 + l31) * 384 + 128 + f) = vk;
+          *reinterpret_cast<bf16x4_t*>(a.dqkv + (row0 + l31) * 384 + 256 + f) = vv;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // Wqkv landed
+  __syncthreads();                                       // dqkv tiles complete
+
+  // ---- da1^T (rows = in-features k of the qkv projection: this wave's 32, cols = tokens)
+  {
+    f32x16_t c[3];
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) c[pp][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int o = ((ks * 2 + kh) ^ sw) << 4;
+#pragma unroll
+      for (int pp = 0; pp < 3; ++pp)
+        c[pp] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<lds_b128_ptr>(L + AB_W + pp * 32768 + (w * 32 + l31) * 256 + o),
+                                                        *reinterpret_cast<lds_b128_ptr>(L + AB_DQKV + pp * 8192 + l31 * 256 + o), c[pp], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4_t v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = f2bf((c[0][4 * g + i] + c[1][4 * g + i]) + c[2][4 * g + i]);
+      *reinterpret_cast<bf16x4_t*>(a.da1 + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g) = v;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
@@ -518,6 +786,23 @@ int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float
     case 8: hipLaunchKernelGGL(attn_block_fwd_kernel<16>, grid, block, 0, st, a); break;
     case 16: hipLaunchKernelGGL(attn_block_fwd_kernel<8>, grid, block, 0, st, a); break;
     default: smd_set_error("attn_block_fwd: num_heads=%d unsupported (4, 8, 16)", num_heads); return -1;
+  }
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_attn_block_bwd(const bf16_t* dh_mid, const bf16_t* qkv, const bf16_t* Wo, const bf16_t* Wqkv, bf16_t* dqkv,
+                          bf16_t* da1, int rows, int num_heads, hipStream_t st) {
+  SMD_ARG_CHECK(dh_mid && qkv && Wo && Wqkv && dqkv && da1, "attn_block_bwd: null pointer");
+  SMD_ARG_CHECK(rows > 0 && rows % S_TOK == 0, "attn_block_bwd: rows=%d must be a multiple of 32", rows);
+  AttnBwdArgs a;
+  a.dh_mid = dh_mid; a.qkv = qkv; a.Wo = Wo; a.Wqkv = Wqkv; a.dqkv = dqkv; a.da1 = da1;
+  const dim3 grid(rows / S_TOK), block(256);
+  switch (num_heads) {
+    case 4: hipLaunchKernelGGL(attn_block_bwd_kernel<32>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(attn_block_bwd_kernel<16>, grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL(attn_block_bwd_kernel<8>, grid, block, 0, st, a); break;
+    default: smd_set_error("attn_block_bwd: num_heads=%d unsupported (4, 8, 16)", num_heads); return -1;
   }
   SMD_LAUNCH_CHECK();
   return 0;

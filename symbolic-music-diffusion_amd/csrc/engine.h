@@ -107,6 +107,7 @@ class SmdEngine {
   int set_side_stream(int enable);
   int group_wgrad = 0;                                        // 1: 128-wide weight gradients in grouped launches at the end
                                                               // of the backward (A/B: -1.6 % -- deferral loses the overlap)
+  int fused_attn_bwd = 1;                                     // attn_block_bwd kernel (0: three separate launches)
   int fused_encoder = 1;                                      // encoder_fused.hip half-layer kernels (0: separate launches)
   int side_wgrad = 0;
 

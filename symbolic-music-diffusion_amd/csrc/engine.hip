@@ -576,9 +576,17 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
       RC(ln_bwd(b, st));
     }
-    RC(dense_bwd(p.out, W.o[l], E, dh_mid, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st, true));
-    RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv[l], B, S, E, d_.num_heads, st));
-    RC(dense_bwd(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
+    if (fused_encoder && fused_attn_bwd && S == 32 && E == 128 && p.out.Np == E && p.qkv.Np == 3 * E) {
+      // out_proj dgrad + attention backward + qkv dgrad in one launch; the two wgrads stay GEMMs
+      RC(wgrad(p.out, W.o[l], E, dh_mid, E, R, true, st));
+      RC(launch_attn_block_bwd(dh_mid, W.qkv[l], wpack_ + p.out.W_off, wpack_ + p.qkv.W_off, W.dqkv[l], W.dA_E, R,
+                               d_.num_heads, st));
+      RC(wgrad(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, true, st));
+    } else {
+      RC(dense_bwd(p.out, W.o[l], E, dh_mid, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st, true));
+      RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv[l], B, S, E, d_.num_heads, st));
+      RC(dense_bwd(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
+    }
     {
       LnBwdArgs b;
       b.f = ln_args(W.h[l], nullptr, R, p.ln1, params_);

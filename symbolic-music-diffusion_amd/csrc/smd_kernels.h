@@ -142,6 +142,11 @@ int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float
                           const bf16_t* Wqkv_t, const float* b_qkv, const bf16_t* Wo_t, const float* b_o, int num_heads,
                           bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st);
 
+// backward of the same half-layer between the two LayerNorms: dqkv (written for the qkv wgrad) and da1 = gradient
+// wrt the LN1 output, from dh_mid (bf16), the saved qkv and the dgrad operand packs Wo [128][128], Wqkv [128][384]
+int launch_attn_block_bwd(const bf16_t* dh_mid, const bf16_t* qkv, const bf16_t* Wo, const bf16_t* Wqkv, bf16_t* dqkv,
+                          bf16_t* da1, int rows, int num_heads, hipStream_t st);
+
 // ------------------------------------------------------------------ diffusion elementwise (diffusion.hip)
 // sinusoidal noise embedding, reference models/ncsn.py:28-41: s[n] -> bf16 [n][channels]
 int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_out, hipStream_t st);

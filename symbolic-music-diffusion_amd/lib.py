@@ -80,6 +80,7 @@ _SIGS = {
                                     c_void, c_void, c_void]),
     "smd_attn_block_fwd": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, c_void,
                                      c_void, c_void, c_void]),
+    "smd_attn_block_bwd": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
     "smd_gemm_bf16_tn": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, c_void, c_void, c_i64, c_void, c_i64, C.c_int, c_void]),
     "smd_gemm_tn_slab_elems": (c_i64, []),

@@ -309,6 +309,37 @@ def test_attn_block_fwd_fused(L, dev, rows, H):
     assert torch.equal(inpl, out)
 
 
+@pytest.mark.parametrize("rows,H", [(32, 8), (96, 16), (64, 4), (2048, 8)])
+def test_attn_block_bwd_fused(L, dev, rows, H):
+    """Fused out_proj dgrad + attention backward + qkv dgrad (encoder_fused.hip) vs fp64 autograd of the attention
+    core on the same bf16 q, k, v (dO rounded to bf16 as in the kernel)."""
+    g = torch.Generator().manual_seed(7 * rows + H)
+    E, d, B = 128, 128 // H, rows // 32
+    qkv = bf(torch.randn(rows, 3 * E, generator=g) * 0.8)
+    dh = bf(torch.randn(rows, E, generator=g) * 0.05)
+    Wo = bf(torch.randn(E, E, generator=g) * 0.09)               # kernel (in, out) == the dgrad pack W [K][N]
+    Wqkv = bf(torch.randn(E, 3 * E, generator=g) * 0.09)
+    do = bf((dh.double() @ Wo.double().t()).float())             # dO[token][in] = sum_out dh[token][out] W[in][out]
+    leaf = qkv.double().clone().requires_grad_(True)
+    q, k, v = [t.view(B, 32, H, d).transpose(1, 2) for t in leaf.split(E, dim=-1)]
+    p = torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(rows, E)
+    (o * do.double()).sum().backward()
+    dqkv_ref = leaf.grad
+    D = lambda t: t.to(dev)
+    dhD, qkvD, WoD, WqD = D(dh), D(qkv), D(Wo), D(Wqkv)
+    dq = torch.zeros(rows, 3 * E, dtype=torch.bfloat16, device=dev)
+    da1 = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_attn_block_bwd(P(dhD), P(qkvD), P(WoD), P(WqD), P(dq), P(da1), rows, H, st()))
+    torch.cuda.synchronize()
+    e_q, e_k, e_v = [rel(dq[:, i * E:(i + 1) * E].float(), dqkv_ref[:, i * E:(i + 1) * E]) for i in range(3)]
+    da1_ref = dq.double().cpu() @ Wqkv.double().t()
+    e_a = rel(da1.float(), da1_ref)
+    print(f"attn_block_bwd rows={rows} H={H}: dq {e_q:.2e} dk {e_k:.2e} dv {e_v:.2e} da1 {e_a:.2e}")
+    assert max(e_q, e_k, e_v) < 1e-2         # p and ds are rounded to bf16 before the matrix-core products
+    assert e_a < 4e-3
+
+
 @pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),
                                           (512, True, True), (1024, True, False)])
 def test_layernorm_fwd_bwd(L, dev, D, film, swish):
