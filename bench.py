@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches for the sample step")
     ap.add_argument("--tr-path", type=int, default=1)
     ap.add_argument("--engine-opt", action="append", default=[], help="extra engine option key=value (A/B runs)")
-    ap.add_argument("--group-wgrad", type=int, default=0, help="128-wide wgrads in grouped launches (0: one launch each)")
+    ap.add_argument("--group-wgrad", type=int, default=2, help="128-wide wgrads: 2 grouped per encoder layer, 1 grouped at the end, 0 one launch each")
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
     return ap.parse_args()
 

@@ -594,6 +594,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       RC(ln_bwd(b, st));
     }
+    if (group_wgrad == 2) RC(flush_grouped_wgrads(st));    // this layer's four 128-wide wgrads as one side-stream launch
   }
   return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dhb[0], E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
 }

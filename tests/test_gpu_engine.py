@@ -93,7 +93,8 @@ def test_loss_and_gradient_parity(arch, C, L, H, K, tr):
     eng = model.train_engine(ema=True)
     eng.set_option("tr_path", 1 if tr == 3 else tr)
     if tr == 3:
-        eng.set_option("group_wgrad", 1)
+        eng.set_option("group_wgrad", 1 if arch == "TransformerDDPM" else 0)
+        eng.set_option("fused_attn_bwd", 0)
         eng.set_option("side_wgrad", 0)
         eng.set_option("fused_encoder", 2 if arch == "TransformerDDPM" else 0)
     eng.set_schedule(BETAS, with_sampler=False)
