@@ -82,6 +82,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
   if (std::string(key) == "side_wgrad") return e->impl.set_side_stream(value);
   if (std::string(key) == "fused_attn_bwd") { e->impl.fused_attn_bwd = value ? 1 : 0; return 0; }
+  if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   smd_set_error("set_option: unknown key '%s'", key);

@@ -105,6 +105,7 @@ class SmdEngine {
   // dgrad / LayerNorm chain.  Every gradient buffer a side wgrad reads has its own slot (no reuse inside a
   // step); the side stream is joined at the end of loss_backward().  0 = single stream.
   int set_side_stream(int enable);
+  int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
                                                               // layer as soon as its backward is enqueued (+4.6 % train), 1 = all at
                                                               // the end of the backward (+3 %), 0 = one launch + reduce each
@@ -128,6 +129,8 @@ class SmdEngine {
   int flush_ln_reduce(hipStream_t st);
   int flush_grouped_wgrads(hipStream_t st);
   std::vector<TnLaunch> deferred_wgrads_;
+  TnLaunch pending256_;
+  bool have_pending256_ = false;
   std::vector<LnReduceEntry> ln_pending_;
   size_t ln_slot_off_ = 0;
   float* P(int64_t off) const { return params_ + off; }

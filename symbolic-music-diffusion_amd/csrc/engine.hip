@@ -71,12 +71,26 @@ int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY
     }
   }
   if (!(allow_side && side_wgrad && side_ && tr_path)) return launch_gemm_tn(t, st);
+  t.slab = W.tn_slab_side;
+  if (pair_wgrad) {                      // a 256x256-kernel problem: wait for its partner (fc2 then fc1 of one DenseResBlock)
+    int per = 0;
+    if (gemm_tn256_plan(t, &per) > 0) {
+      if (!have_pending256_) { pending256_ = t; have_pending256_ = true; return 0; }
+      have_pending256_ = false;
+      hipEvent_t ev2 = take_event();
+      SMD_ARG_CHECK(ev2, "wgrad: cannot create an event");
+      hipError_t e2 = hipEventRecord(ev2, st);
+      if (e2 == hipSuccess) e2 = hipStreamWaitEvent(side_, ev2, 0);
+      if (e2 != hipSuccess) { smd_set_error("wgrad: event: %s", hipGetErrorString(e2)); return (int)e2; }
+      side_pending_ = true;
+      return launch_gemm_tn256_pair(pending256_, t, side_);
+    }
+  }
   hipEvent_t ev = take_event();
   SMD_ARG_CHECK(ev, "wgrad: cannot create an event");
   hipError_t e = hipEventRecord(ev, st);
   if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
   if (e != hipSuccess) { smd_set_error("wgrad: event: %s", hipGetErrorString(e)); return (int)e; }
-  t.slab = W.tn_slab_side;
   side_pending_ = true;
   return launch_gemm_tn(t, side_);
 }
@@ -104,6 +118,16 @@ int SmdEngine::flush_grouped_wgrads(hipStream_t st) {
 }
 
 int SmdEngine::join_side(hipStream_t st) {
+  if (have_pending256_) {                // an unpaired 256x256 problem
+    have_pending256_ = false;
+    hipEvent_t ev0 = take_event();
+    SMD_ARG_CHECK(ev0, "join_side: cannot create an event");
+    hipError_t e0 = hipEventRecord(ev0, st);
+    if (e0 == hipSuccess) e0 = hipStreamWaitEvent(side_, ev0, 0);
+    if (e0 != hipSuccess) { smd_set_error("join_side: %s", hipGetErrorString(e0)); return (int)e0; }
+    side_pending_ = true;
+    RC(launch_gemm_tn(pending256_, side_));
+  }
   if (!side_pending_) { next_event_ = 0; return 0; }
   hipEvent_t ev = take_event();
   SMD_ARG_CHECK(ev, "join_side: cannot create an event");

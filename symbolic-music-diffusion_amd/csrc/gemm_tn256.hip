@@ -96,13 +96,20 @@ struct Tn256Args {
   int tiles_n, tiles_k, ktiles_per_split, nwg;
 };
 
-__global__ __launch_bounds__(512) void gemm_tn256_kernel(Tn256Args a) {
+// Up to two problems per launch (the two Dense layers of one DenseResBlock): with 2 x 64 tiles two m-splits fill
+// the chip, which halves the slab traffic of a lone problem's four splits.
+struct Tn256Group { int ngroups; int nwg_total; Tn256Args p[2]; };
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(Tn256Group ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
-  // flattened (split, tile) id, XCD-remapped: one XCD's blocks share an m-range and neighbouring tiles
+  // flattened (problem, split, tile) id, XCD-remapped: one XCD's blocks share an m-range and neighbouring tiles
   const int bid = blockIdx.x;
-  const int q = a.nwg >> 3, r = a.nwg & 7, xcd = bid & 7;
-  const int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int q = ga.nwg_total >> 3, r = ga.nwg_total & 7, xcd = bid & 7;
+  int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int gsel = (ga.ngroups > 1 && vid >= ga.p[0].nwg) ? 1 : 0;
+  if (gsel) vid -= ga.p[0].nwg;
+  const Tn256Args a = ga.p[gsel];
   const int tiles = a.tiles_k * a.tiles_n;
   const int split = vid / tiles, tile = vid - split * tiles;
   const int tk = tile / a.tiles_n, tn = tile - tk * a.tiles_n;
@@ -362,21 +369,58 @@ int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split) {
   return nsplit;
 }
 
-int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st) {
-  Tn256Args a;
+static void fill_tn256(Tn256Args& a, const TnLaunch& t, int nsplit, int per, float* slab) {
   a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
-  a.tiles_k = t.Kd / TM; a.tiles_n = t.N / TN; a.ktiles_per_split = ktiles_per_split;
+  a.tiles_k = t.Kd / TM; a.tiles_n = t.N / TN; a.ktiles_per_split = per;
   a.nwg = a.tiles_k * a.tiles_n * nsplit;
   const size_t n_w = (size_t)t.Kd * t.N;
-  float* bias_part = t.slab + (size_t)nsplit * n_w;
-  a.dst = t.slab; a.ld = t.N; a.split_stride = n_w;
-  a.bias_dst = t.bias_out ? bias_part : nullptr;
-  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(a.nwg), dim3(512), 0, st, a);
-  SMD_LAUNCH_CHECK();
-  const size_t n_w4 = n_w / 4;
+  a.dst = slab; a.ld = t.N; a.split_stride = n_w;
+  a.bias_dst = t.bias_out ? slab + (size_t)nsplit * n_w : nullptr;
+}
+static int reduce_tn256(const TnLaunch& t, const Tn256Args& a, int nsplit, hipStream_t st) {
+  const size_t n_w = (size_t)t.Kd * t.N, n_w4 = n_w / 4;
   const size_t total = n_w4 + (t.bias_out ? (size_t)t.N / 4 : 0);
-  hipLaunchKernelGGL(reduce_slabs256_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, t.slab, n_w, nsplit,
-                     n_w4, t.out, t.ldo, t.N, bias_part, nsplit * a.tiles_k, t.bias_out);
+  hipLaunchKernelGGL(reduce_slabs256_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.dst, n_w, nsplit,
+                     n_w4, t.out, t.ldo, t.N, a.dst + (size_t)nsplit * n_w, nsplit * a.tiles_k, t.bias_out);
   SMD_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st) {
+  Tn256Group ga;
+  ga.ngroups = 1;
+  fill_tn256(ga.p[0], t, nsplit, ktiles_per_split, t.slab);
+  ga.nwg_total = ga.p[0].nwg;
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), 0, st, ga);
+  SMD_LAUNCH_CHECK();
+  return reduce_tn256(t, ga.p[0], nsplit, st);
+}
+
+// Two tn256-eligible problems of the same shape class in one launch (slabs carved from t0.slab).
+int launch_gemm_tn256_pair(const TnLaunch& t0, const TnLaunch& t1, hipStream_t st) {
+  int per0 = 0, per1 = 0;
+  const int n0 = gemm_tn256_plan(t0, &per0), n1 = gemm_tn256_plan(t1, &per1);
+  SMD_ARG_CHECK(n0 > 0 && n1 > 0, "gemm_tn256_pair: problem not eligible for the 256x256 kernel");
+  const int tiles0 = (t0.Kd / TM) * (t0.N / TN), tiles1 = (t1.Kd / TM) * (t1.N / TN);
+  const int total_kt = (t0.Mrows + TKM - 1) / TKM;
+  SMD_ARG_CHECK(t0.Mrows == t1.Mrows, "gemm_tn256_pair: different contraction lengths");
+  int nsplit = (256 + tiles0 + tiles1 - 1) / (tiles0 + tiles1);
+  if (nsplit * 4 > total_kt) nsplit = total_kt / 4;
+  if (nsplit < 1) nsplit = 1;
+  int per = (total_kt + nsplit - 1) / nsplit;
+  per = (per + 1) & ~1;
+  nsplit = (total_kt + per - 1) / per;
+  const size_t need0 = (size_t)nsplit * t0.Kd * t0.N + (size_t)nsplit * (t0.Kd / TM) * t0.N;
+  const size_t need1 = (size_t)nsplit * t1.Kd * t1.N + (size_t)nsplit * (t1.Kd / TM) * t1.N;
+  SMD_ARG_CHECK(need0 + need1 <= t0.slab_elems, "gemm_tn256_pair: slab workspace too small");
+  Tn256Group ga;
+  ga.ngroups = 2;
+  fill_tn256(ga.p[0], t0, nsplit, per, t0.slab);
+  fill_tn256(ga.p[1], t1, nsplit, per, t0.slab + ((need0 + 3) / 4 * 4));
+  ga.nwg_total = ga.p[0].nwg + ga.p[1].nwg;
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), 0, st, ga);
+  SMD_LAUNCH_CHECK();
+  int rc = reduce_tn256(t0, ga.p[0], nsplit, st);
+  if (rc) return rc;
+  return reduce_tn256(t1, ga.p[1], nsplit, st);
 }

@@ -64,6 +64,7 @@ size_t gemm_tn_slab_elems();
 // 256x256 8-phase wgrad kernel (gemm_tn256.hip): plan returns nsplit (0 = not eligible)
 int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split);
 int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st);
+int launch_gemm_tn256_pair(const TnLaunch& t0, const TnLaunch& t1, hipStream_t st);   // two problems, one launch
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st);
 // n wgrad problems with the same Mrows (ldo == N each) in grouped launches of the 128-wide kernel + one reduce
 int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st);
