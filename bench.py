@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches for the sample step")
     ap.add_argument("--tr-path", type=int, default=1)
+    ap.add_argument("--tuning", action="append", default=[], help="process-wide kernel knob key=value (smd_set_tuning)")
     ap.add_argument("--engine-opt", action="append", default=[], help="extra engine option key=value (A/B runs)")
     ap.add_argument("--group-wgrad", type=int, default=2, help="128-wide wgrads: 2 grouped per encoder layer, 1 grouped at the end, 0 one launch each")
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
@@ -122,6 +123,9 @@ def main():
     from smd_amd.engine import NetConfig
     from smd_amd.trainer import GradComm, create_optimizer, train_step
 
+    for kv in a.tuning:
+        k, _, v = kv.partition("=")
+        lib.check(lib.get_lib().smd_set_tuning(k.encode(), int(v)))
     kw = dict() if a.config == "base" else dict(num_layers=8, num_heads=16, num_mlp_layers=3)
     cfg = NetConfig(architecture="TransformerDDPM", data_channels=512, seq_len=32, num_timesteps=1000, **kw)
     model = N.Model(cfg, dev, seed=0)

@@ -105,6 +105,7 @@ class SmdEngine {
   // dgrad / LayerNorm chain.  Every gradient buffer a side wgrad reads has its own slot (no reuse inside a
   // step); the side stream is joined at the end of loss_backward().  0 = single stream.
   int set_side_stream(int enable);
+  int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
                                                               // layer as soon as its backward is enqueued (+4.6 % train), 1 = all at
@@ -197,9 +198,9 @@ class SmdEngine {
     bf16_t* do_ = nullptr;                // [R][E]
     std::vector<bf16_t*> dz1;             // [L] x [R][M]
     std::vector<float*> dss;              // [B][2M]
-    bf16_t* dss_bf16 = nullptr;           // [B][2M]
-    bf16_t* dp = nullptr;                 // [B][4F]
-    bf16_t* df1 = nullptr;                // [B][4F]
+    std::vector<bf16_t*> dss_bf16;        // [K] x [B][2M]
+    std::vector<bf16_t*> dp;              // [K] x [B][4F]
+    std::vector<bf16_t*> df1;             // [K] x [B][4F]
     float* ln_partial = nullptr;
     size_t ln_partial_elems = 0;
     float* tn_slab = nullptr;             // split-K partial tiles of the wgrad kernel (main stream)

@@ -3,6 +3,10 @@
 // reverse-diffusion iteration (utils/ebm_utils.py:327-394).  See engine.h.
 #include "engine.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <cmath>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -112,7 +116,16 @@ int SmdEngine::flush_grouped_wgrads(hipStream_t st) {
     side_pending_ = true;
   }
   for (TnLaunch& t : deferred_wgrads_) t.slab = slab;
-  const int rc = launch_gemm_tn_grouped(deferred_wgrads_.data(), (int)deferred_wgrads_.size(), ls);
+  // a grouped launch shares one contraction length: batch-row problems (FiLM generators) and token-row problems apart
+  std::stable_sort(deferred_wgrads_.begin(), deferred_wgrads_.end(),
+                   [](const TnLaunch& x, const TnLaunch& y) { return x.Mrows < y.Mrows; });
+  int rc = 0;
+  for (size_t i = 0; i < deferred_wgrads_.size() && rc == 0;) {
+    size_t j = i;
+    while (j < deferred_wgrads_.size() && deferred_wgrads_[j].Mrows == deferred_wgrads_[i].Mrows) ++j;
+    rc = launch_gemm_tn_grouped(deferred_wgrads_.data() + i, (int)(j - i), ls);
+    i = j;
+  }
   deferred_wgrads_.clear();
   return rc;
 }
@@ -269,9 +282,12 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     for (auto& p : t.do1) p = c.take<bf16_t>(R * M);
     t.dss.resize(K);
     for (auto& p : t.dss) p = c.take<float>(B * 2 * M);
-    t.dss_bf16 = c.take<bf16_t>(B * 2 * M);
-    t.dp = c.take<bf16_t>(B * 4 * F);
-    t.df1 = c.take<bf16_t>(B * 4 * F);
+    t.dss_bf16.resize(K); t.dp.resize(K); t.df1.resize(K);      // per block: their wgrads run late (side stream)
+    for (int k = 0; k < K; ++k) {
+      t.dss_bf16[k] = c.take<bf16_t>(B * 2 * M);
+      t.dp[k] = c.take<bf16_t>(B * 4 * F);
+      t.df1[k] = c.take<bf16_t>(B * 4 * F);
+    }
     if (L > 0) {
       t.dh = c.take<float>(R * E);
       t.dhb.resize(2 * L + 1);
@@ -510,7 +526,14 @@ int SmdEngine::ln_bwd(LnBwdArgs& b, hipStream_t st) {
   ln_slot_off_ += need;
   ln_pending_.emplace_back();
   b.deferred = &ln_pending_.back();
-  return launch_layernorm_bwd(b, st);
+  // SMD_DEBUG_SYNC (bit 1: drain the main stream before every LayerNorm backward, 2: drain the side stream, 4: drain
+  // after it) exists for tools/det_check.py -- see DESIGN.md section 6, "known issue"
+  static const int dbg = getenv("SMD_DEBUG_SYNC") ? atoi(getenv("SMD_DEBUG_SYNC")) : 0;
+  if (dbg & 1) (void)hipStreamSynchronize(st);          // debug: main chain drained before the LN backward
+  if ((dbg & 2) && side_) (void)hipStreamSynchronize(side_);   // debug: side stream idle during the LN backward
+  const int rc = launch_layernorm_bwd(b, st);
+  if (dbg & 4) (void)hipStreamSynchronize(st);          // debug: LN backward complete before anything else is enqueued
+  return rc;
 }
 int SmdEngine::flush_ln_reduce(hipStream_t st) {
   if (ln_pending_.empty()) return 0;
@@ -561,10 +584,10 @@ int SmdEngine::backward_head(hipStream_t st) {
       RC(ln_bwd(b, st));
     }
     // FiLM generator (models/ncsn.py:52-61)
-    RC(launch_cast_pad_bf16(W.dss[k], B, 2 * M, W.dss_bf16, 2 * M, st));
-    RC(dense_bwd(p.ss, W.p[k], 4 * F, W.dss_bf16, 2 * M, B, W.dp, 4 * F, nullptr, 0, SMD_AUX_NONE, st));
-    RC(dense_bwd(p.f2, W.f1[k], 4 * F, W.dp, 4 * F, B, W.df1, 4 * F, W.zf1[k], 4 * F, SMD_AUX_SWISH_GRAD, st));
-    RC(dense_bwd(p.f1, W.emb, F, W.df1, 4 * F, B, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st));
+    RC(launch_cast_pad_bf16(W.dss[k], B, 2 * M, W.dss_bf16[k], 2 * M, st));
+    RC(dense_bwd(p.ss, W.p[k], 4 * F, W.dss_bf16[k], 2 * M, B, W.dp[k], 4 * F, nullptr, 0, SMD_AUX_NONE, st, film_side != 0));
+    RC(dense_bwd(p.f2, W.f1[k], 4 * F, W.dp[k], 4 * F, B, W.df1[k], 4 * F, W.zf1[k], 4 * F, SMD_AUX_SWISH_GRAD, st, film_side != 0));
+    RC(dense_bwd(p.f1, W.emb, F, W.df1[k], 4 * F, B, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, film_side != 0));
   }
   if (d_.arch == 0) {
     // up (models/ncsn.py:171) and ln_f (:170)

@@ -410,10 +410,12 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 // the P/Q column accumulators (see the wide kernel) are folded over the row slots with two more shuffles.
 __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a) {
   constexpr int D = 128;
-  __shared__ float red[4][2][D];
+  __shared__ float red[16][2][D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int sub = lane >> 4, c0 = (lane & 15) * 8;
-  const int grp = blockIdx.x;
+  // XCD-banded row groups (block b runs on XCD b % 8): XCD x owns the contiguous band of groups [x*n/8, (x+1)*n/8),
+  // the same band -> XCD affinity the row-tiled GEMMs use, so a row block is produced and consumed through one L2
+  const int grp = smd_xcd_band(blockIdx.x, gridDim.x);
   const int r_begin = grp * a.group_rows;             // group_rows == 32
   float g[8];
   {
@@ -445,8 +447,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
       r[it][0] = t0.x; r[it][1] = t0.y; r[it][2] = t0.z; r[it][3] = t0.w; r[it][4] = t1.x; r[it][5] = t1.y; r[it][6] = t1.z; r[it][7] = t1.w;
     }
   }
+  // all-reduce over the 16 lanes of a row with DPP (one DPP "row" == 16 lanes): xor-1 / xor-2 inside the quad, then
+  // half-mirror (quad pairs) and mirror (row halves); every step adds two commuting operands, so all 16 lanes end
+  // with the bitwise identical sum.  No ds_bpermute: the LDS crossbar is shared with co-resident workgroups.
   auto sum16 = [](float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
     return v;
   };
 #pragma unroll
@@ -488,20 +496,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
       }
     }
   }
-  // fold the 4 row slots of the wave (fixed order), then the 4 waves through LDS
+  // the 16 row slots of the workgroup (4 waves x 4) are folded through LDS in a fixed order
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    P[i] += __shfl_xor(P[i], 16, 64); P[i] += __shfl_xor(P[i], 32, 64);
-    Q[i] += __shfl_xor(Q[i], 16, 64); Q[i] += __shfl_xor(Q[i], 32, 64);
-  }
-  if (sub == 0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { red[w][0][c0 + i] = P[i]; red[w][1][c0 + i] = Q[i]; }
-  }
+  for (int i = 0; i < 8; ++i) { red[w * 4 + sub][0][c0 + i] = P[i]; red[w * 4 + sub][1][c0 + i] = Q[i]; }
   __syncthreads();
   {
     const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
-    a.partial[((size_t)grp * 2 + which) * D + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    float acc = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) acc += red[sl][which][c];
+    a.partial[((size_t)grp * 2 + which) * D + c] = acc;
   }
 }
 
@@ -611,7 +615,7 @@ int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
   d.dfilm_accumulate = a.dfilm_accumulate;
   d.partial = a.partial;
   d.group_rows = gr;
-  if (a.f.D == 128 && !a.f.film_scale && !a.f.swish && gr == 32 && smd_tuning_get("ln_bwd_wide")) {
+  if (a.f.D == 128 && !a.f.film_scale && !a.f.swish && gr == 32 && smd_tuning_get("ln_bwd_narrow")) {
     hipLaunchKernelGGL(layernorm_bwd_narrow128_kernel, dim3(ngroups), dim3(256), 0, st, d);
   } else {
     SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st));

@@ -32,6 +32,13 @@ void smd_set_error(const char* fmt, ...);
     }                                                                          \
   } while (0)
 
+// ---- XCD-aware work distribution: hardware places block b on XCD b % 8; this bijection gives XCD x the contiguous
+// band [x*n/8, (x+1)*n/8) of a 1-D index space (the mapping every row-tiled kernel here uses) ----
+__device__ __forceinline__ int smd_xcd_band(int bid, int n) {
+  const int q = n >> 3, r = n & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // ---- scalar math ----
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
