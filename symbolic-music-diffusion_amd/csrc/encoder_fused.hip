@@ -237,6 +237,192 @@ __global__ __launch_bounds__(256) void mlp_block_fwd_kernel(MlpArgs a) {
 }
 
 
+
+// ---- 8-wave variant of the MLP half-layer on 16x16x32 MFMAs: two waves per SIMD hide each other's MFMA / LDS /
+// transcendental latencies (the 4-wave kernel above runs one wave per SIMD and is bound by exactly those).
+// Wave w = (hg = w & 3: 32 hidden units of the chunk, th = w >> 2: token half).  z^T tiles [16 hidden x 16 tokens]
+// (C layout: lane = token column, 4 hidden rows) of the two m-tiles form the 8-element A fragment of the second
+// GEMM (k permutation: element s <-> hidden 4g + s, 16 + 4g + s - 4).  Training saves (z1, u) are staged through
+// LDS per chunk so that every thread writes 16 contiguous bytes of a 256-B row segment.
+constexpr int M8_STAGE = OFF_A2 + S_TOK * E_DIM * 2;           // z1 | u staging tiles: 2 x [32][256 B]
+constexpr int M8_SMEM = M8_STAGE + 2 * 8192;
+
+template <bool SAVE>
+__global__ __launch_bounds__(512) void mlp_block_fwd8_kernel(MlpArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[M8_SMEM];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hg = w & 3, th = w >> 2;
+  const size_t row0 = (size_t)blockIdx.x * S_TOK;
+  const int g = lane >> 4, j = lane & 15;
+  lds_byte_ptr L = (lds_byte_ptr)smem;
+
+  // ---- weight DMA: 4 rounds per slice, round r covers LDS rows r*32 + w*4 + (lane>>4)
+  const int rl = w * 4 + (lane >> 4);                                    // 0..31 ; row & 15 == rl & 15
+  const uint32_t cs = (uint32_t)(((lane & 15) ^ (rl & 15)) * 16);
+  const uint32_t w1_v = (uint32_t)rl * 256u + cs;
+  const uint32_t w2_v = (uint32_t)rl * (uint32_t)(a.M * 2) + cs;
+  const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1t), 0, a.M * E_DIM * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2t), 0, a.M * E_DIM * 2, 0x00020000);
+  const uint32_t w2_round = (uint32_t)(32 * a.M * 2);
+  unsigned char* lds_w = smem + w * 1024;
+  auto stage_chunk = [&](int c, int buf) {
+    unsigned char* d1 = lds_w + buf * BUF_BYTES;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) glds16(w1_rsrc, w1_v, (uint32_t)(c * W_SLICE + r * 8192), d1 + r * 8192);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) glds16(w2_rsrc, w2_v, (uint32_t)(c * 256) + r * w2_round, d1 + W_SLICE + r * 8192);
+  };
+  const int nchunks = a.M / CH;
+  float4 bnext[2];
+  auto fetch_bias = [&](int c) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) bnext[mt] = *reinterpret_cast<const float4*>(a.b1 + c * CH + hg * 32 + mt * 16 + 4 * g);
+  };
+  fetch_bias(0);
+  stage_chunk(0, 0);
+
+  // ---- LayerNorm: wave w normalises rows w*4 .. +4 -> a2 tile
+  {
+    const float2 g2 = *reinterpret_cast<const float2*>(a.gamma + lane * 2);
+    const float2 b2v = *reinterpret_cast<const float2*>(a.beta + lane * 2);
+    float2 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 4 + i) * E_DIM + lane * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = w * 4 + i;
+      float s = x[i].x + x[i].y, s2 = x[i].x * x[i].x + x[i].y * x[i].y;
+      s = wave_sum(s);
+      s2 = wave_sum(s2);
+      const float mean = s * (1.0f / E_DIM);
+      const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      bf16x2_t o;
+      o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
+      o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
+      *reinterpret_cast<bf16x2_t*>(smem + OFF_A2 + r * 256 + (((lane >> 2) ^ (r & 15)) << 4) + (lane & 3) * 4) = o;
+      if (a.save_a2) *reinterpret_cast<bf16x2_t*>(a.save_a2 + (row0 + r) * E_DIM + lane * 2) = o;
+    }
+  }
+  __syncthreads();
+
+  // B fragments of a2^T (lane = token th*16 + j, k-chunk 4*ks + g), 4 k-steps of 32
+  bf16x8_t a2f[4];
+  {
+    const int tok = th * 16 + j;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a2f[ks] = *reinterpret_cast<lds_b128_ptr>(L + OFF_A2 + tok * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
+  }
+  f32x4_t acc_o[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc_o[t][e] = 0.0f;
+
+  const int stok = tid >> 4, spc = tid & 15;          // staged-save mapping: thread -> (token, 16-B piece of a 256-B row)
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    float4 bcur[2] = {bnext[0], bnext[1]};
+    if (c + 1 < nchunks) {
+      fetch_bias(c + 1);
+      stage_chunk(c + 1, buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // the 2 bias loads + 8 DMAs just issued may stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (SAVE && c > 0) {
+      // z1 / u of the previous chunk: LDS staging -> registers -> 16-byte global stores that drain behind this
+      // chunk's compute (the next vmcnt wait is a whole iteration away)
+      const bf16x8_t vz = *reinterpret_cast<lds_b128_ptr>(L + M8_STAGE + stok * 256 + spc * 16);
+      const bf16x8_t vu = *reinterpret_cast<lds_b128_ptr>(L + M8_STAGE + 8192 + stok * 256 + spc * 16);
+      __builtin_amdgcn_s_barrier();      // everybody has read the staging tiles before this chunk rewrites them
+      *reinterpret_cast<bf16x8_t*>(a.save_z1 + (row0 + stok) * a.M + (c - 1) * CH + spc * 8) = vz;
+      *reinterpret_cast<bf16x8_t*>(a.save_u + (row0 + stok) * a.M + (c - 1) * CH + spc * 8) = vu;
+    }
+    lds_byte_ptr s1 = L + buf * BUF_BYTES;
+    lds_byte_ptr s2 = s1 + W_SLICE;
+
+    // z^T tiles: rows = hidden hg*32 + mt*16 + (0..15), cols = tokens th*16 + (0..15)
+    f32x4_t z[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[mt][e] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const bf16x8_t wf = *reinterpret_cast<lds_b128_ptr>(s1 + (hg * 32 + mt * 16 + j) * 256 + (((ks * 4 + g) ^ j) << 4));
+        z[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, a2f[ks], z[mt], 0, 0, 0);
+      }
+    // bias, GELU -> A fragment of the second GEMM; hidden of z[mt][e]: hg*32 + mt*16 + 4g + e
+    Frag8 uf;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float bb[4] = {bcur[mt].x, bcur[mt].y, bcur[mt].z, bcur[mt].w};
+      bf16x4_t zz, uu;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = z[mt][e] + bb[e];
+        zz[e] = f2bf(v);
+        uu[e] = f2bf(geluf_(v));
+      }
+      uf.h[mt] = uu;
+      if (SAVE) {
+        const int tok = th * 16 + j, hcol = hg * 32 + mt * 16 + 4 * g;          // 4 consecutive hidden of this chunk
+        const int off = tok * 256 + hcol * 2;
+        *reinterpret_cast<bf16x4_t*>(smem + M8_STAGE + off) = zz;
+        *reinterpret_cast<bf16x4_t*>(smem + M8_STAGE + 8192 + off) = uu;
+      }
+    }
+    // h_part[token][n] += u[token][this wave's 32 hidden] * W2[hidden][n]
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      const int n = nt * 16 + j;
+      const int ch = hg * 4 + (g >> 1);
+      Frag8 bf;
+      bf.h[0] = *reinterpret_cast<lds_b64_ptr>(s2 + n * 256 + ((ch ^ j) << 4) + (g & 1) * 8);
+      bf.h[1] = *reinterpret_cast<lds_b64_ptr>(s2 + n * 256 + (((ch + 2) ^ j) << 4) + (g & 1) * 8);
+      acc_o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf.v, bf.v, acc_o[nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();      // `buf` free for the next refill; the staging tiles are complete
+  }
+  if (SAVE) {                          // the last chunk's staging tiles
+    const bf16x8_t vz = *reinterpret_cast<lds_b128_ptr>(L + M8_STAGE + stok * 256 + spc * 16);
+    const bf16x8_t vu = *reinterpret_cast<lds_b128_ptr>(L + M8_STAGE + 8192 + stok * 256 + spc * 16);
+    *reinterpret_cast<bf16x8_t*>(a.save_z1 + (row0 + stok) * a.M + (nchunks - 1) * CH + spc * 8) = vz;
+    *reinterpret_cast<bf16x8_t*>(a.save_u + (row0 + stok) * a.M + (nchunks - 1) * CH + spc * 8) = vu;
+  }
+
+  // ---- sum the four hidden-group partials of each token half through LDS, + b2 + residual
+  float* red = reinterpret_cast<float*>(smem);           // [4 hg][32 tokens][128] fp32 = 64 KiB
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(hg * S_TOK + th * 16 + 4 * g + e) * E_DIM + nt * 16 + j] = acc_o[nt][e];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int idx = (i * 512 + tid) * 4;
+    const int tok = idx >> 7, col = idx & 127;
+    const float4 p0 = *reinterpret_cast<const float4*>(red + (0 * S_TOK + tok) * E_DIM + col);
+    const float4 p1 = *reinterpret_cast<const float4*>(red + (1 * S_TOK + tok) * E_DIM + col);
+    const float4 p2 = *reinterpret_cast<const float4*>(red + (2 * S_TOK + tok) * E_DIM + col);
+    const float4 p3 = *reinterpret_cast<const float4*>(red + (3 * S_TOK + tok) * E_DIM + col);
+    const float4 bb = *reinterpret_cast<const float4*>(a.b2 + col);
+    const float4 hr = *reinterpret_cast<const float4*>(a.h_in + (row0 + tok) * E_DIM + col);
+    float4 o;
+    o.x = ((p0.x + p1.x) + (p2.x + p3.x)) + bb.x + hr.x;
+    o.y = ((p0.y + p1.y) + (p2.y + p3.y)) + bb.y + hr.y;
+    o.z = ((p0.z + p1.z) + (p2.z + p3.z)) + bb.z + hr.z;
+    o.w = ((p0.w + p1.w) + (p2.w + p3.w)) + bb.w + hr.w;
+    *reinterpret_cast<float4*>(a.h_out + (row0 + tok) * E_DIM + col) = o;
+  }
+}
+
 // =====================================================================================================
 //   attn_block_fwd:  h_mid = h_in + out_proj( softmax(q k^T / sqrt(d)) v ),  q,k,v = Dense(LN(h_in))     (:159-162)
 //
@@ -763,10 +949,18 @@ int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float*
   MlpArgs a;
   a.h_in = h_in; a.h_out = h_out; a.gamma = gamma; a.beta = beta; a.W1t = W1t; a.b1 = b1; a.W2t = W2t; a.b2 = b2; a.M = M;
   a.save_a2 = save_a2; a.save_z1 = save_z1; a.save_u = save_u;
-  switch (smd_tuning_get("mlp_variant")) {
-    case 1: hipLaunchKernelGGL(mlp_block_fwd_kernel<1>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(mlp_block_fwd_kernel<2>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(mlp_block_fwd_kernel<0>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+  const int variant = smd_tuning_get("mlp_variant");
+  if (variant == 0) {        // 8-wave kernel (default); saves need all three pointers
+    const bool save = save_z1 && save_u;
+    SMD_ARG_CHECK(save || (!save_z1 && !save_u), "mlp_block_fwd: save_z1 and save_u come together");
+    if (save) hipLaunchKernelGGL(mlp_block_fwd8_kernel<true>, dim3(rows / S_TOK), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(mlp_block_fwd8_kernel<false>, dim3(rows / S_TOK), dim3(512), 0, st, a);
+  } else {
+    switch (variant) {
+      case 1: hipLaunchKernelGGL(mlp_block_fwd_kernel<1>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+      case 2: hipLaunchKernelGGL(mlp_block_fwd_kernel<2>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+      default: hipLaunchKernelGGL(mlp_block_fwd_kernel<0>, dim3(rows / S_TOK), dim3(256), 0, st, a); break;
+    }
   }
   SMD_LAUNCH_CHECK();
   return 0;

@@ -42,7 +42,9 @@ int SmdEngine::set_side_stream(int enable) {
   if (enable && !side_) {
     int lo = 0, hi = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least priority (numerically largest)
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, lo);
+    const char* pr = getenv("SMD_SIDE_PRIORITY");            // "normal": same priority as the main stream (debug / A-B)
+    if (e == hipSuccess) e = (pr && !strcmp(pr, "normal")) ? hipStreamCreateWithFlags(&side_, hipStreamNonBlocking)
+                                                           : hipStreamCreateWithPriority(&side_, hipStreamNonBlocking, lo);
     if (e != hipSuccess) { smd_set_error("set_side_stream: %s", hipGetErrorString(e)); side_ = nullptr; return (int)e; }
   }
   side_wgrad = enable ? 1 : 0;

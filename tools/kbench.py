@@ -70,7 +70,7 @@ def main():
         out = torch.empty(R, 128, device=dev)
         sa = torch.empty(R, 128, dtype=torch.bfloat16, device=dev)
         sz, su = torch.empty(R, M, dtype=torch.bfloat16, device=dev), torch.empty(R, M, dtype=torch.bfloat16, device=dev)
-        for save, var in ((0, 0), (1, 0), (0, 1), (0, 2)):
+        for save, var in ((0, 0), (1, 0), (0, 3), (1, 3)):
             lib.check(L.smd_set_tuning(b"mlp_variant", var))
             f = lambda: lib.check(L.smd_mlp_block_fwd(h.data_ptr(), out.data_ptr(), R, g.data_ptr(), b.data_ptr(), W1t.data_ptr(),
                                                       b1.data_ptr(), W2t.data_ptr(), b2.data_ptr(), M,
