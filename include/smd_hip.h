@@ -169,6 +169,13 @@ int smd_layernorm_bwd(const float* x, int rows, int D, const float* gamma, const
 int smd_layernorm_bwd_ex(const float* x, const smd_bf16* x_bf16, int rows, int D, const float* gamma, const float* beta,
                          const smd_bf16* dout, const float* dres, float* dx, smd_bf16* dx_bf16, float* dgamma, float* dbeta,
                          float* partial, int64_t partial_elems, void* stream);
+/* ... and the ResBlock form (models/shared.py:62-68): FiLM + swish, bf16 or fp32 input, the residual gradient in fp32
+ * (`dres`) or bf16 (`dres_bf16`, D in {1024, 2048}), fp32 and/or bf16 dx; dfilm_accumulate: dscale/dshift += */
+int smd_layernorm_bwd_film(const float* x, const smd_bf16* x_bf16, int rows, int D, const float* gamma, const float* beta,
+                           const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample, int swish,
+                           const smd_bf16* dout, const float* dres, const smd_bf16* dres_bf16, float* dx,
+                           smd_bf16* dx_bf16, float* dgamma, float* dbeta, float* dscale, float* dshift,
+                           int dfilm_accumulate, float* partial, int64_t partial_elems, void* stream);
 int smd_attention_fwd(const smd_bf16* qkv, smd_bf16* out, int B, int S, int E, int H, void* stream);
 int smd_attention_bwd(const smd_bf16* qkv, const smd_bf16* dout, smd_bf16* dqkv, int B, int S, int E, int H,
                       void* stream);

@@ -82,6 +82,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
   if (std::string(key) == "side_wgrad") return e->impl.set_side_stream(value);
   if (std::string(key) == "fused_attn_bwd") { e->impl.fused_attn_bwd = value ? 1 : 0; return 0; }
+  if (std::string(key) == "resgrad_bf16") { e->impl.resgrad_bf16 = value ? 1 : 0; return 0; }
   if (std::string(key) == "film_side") { e->impl.film_side = value; return 0; }
   if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
@@ -206,6 +207,20 @@ int smd_layernorm_bwd_ex(const float* x, const smd_bf16* x_bf16, int rows, int D
   LnBwdArgs b;
   b.f.x = x; b.f.x_bf16 = B(x_bf16); b.f.rows = rows; b.f.D = D; b.f.gamma = gamma; b.f.beta = beta;
   b.dout = B(dout); b.dres = dres; b.dx = dx; b.dx_bf16 = B(dx_bf16); b.dgamma = dgamma; b.dbeta = dbeta;
+  b.partial = partial; b.partial_elems = (size_t)partial_elems;
+  return launch_layernorm_bwd(b, S(stream));
+}
+int smd_layernorm_bwd_film(const float* x, const smd_bf16* x_bf16, int rows, int D, const float* gamma, const float* beta,
+                           const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample, int swish,
+                           const smd_bf16* dout, const float* dres, const smd_bf16* dres_bf16, float* dx,
+                           smd_bf16* dx_bf16, float* dgamma, float* dbeta, float* dscale, float* dshift,
+                           int dfilm_accumulate, float* partial, int64_t partial_elems, void* stream) {
+  LnBwdArgs b;
+  b.f.x = x; b.f.x_bf16 = B(x_bf16); b.f.rows = rows; b.f.D = D; b.f.gamma = gamma; b.f.beta = beta;
+  b.f.film_scale = film_scale; b.f.film_shift = film_shift; b.f.ld_film = ld_film; b.f.rows_per_sample = rows_per_sample;
+  b.f.swish = swish;
+  b.dout = B(dout); b.dres = dres; b.dres_bf16 = B(dres_bf16); b.dx = dx; b.dx_bf16 = B(dx_bf16);
+  b.dgamma = dgamma; b.dbeta = dbeta; b.dscale = dscale; b.dshift = dshift; b.dfilm_accumulate = dfilm_accumulate;
   b.partial = partial; b.partial_elems = (size_t)partial_elems;
   return launch_layernorm_bwd(b, S(stream));
 }

@@ -111,6 +111,7 @@ class SmdEngine {
                                                               // layer as soon as its backward is enqueued (+4.6 % train), 1 = all at
                                                               // the end of the backward (+3 %), 0 = one launch + reduce each
   int fused_attn_bwd = 1;                                     // attn_block_bwd kernel (0: three separate launches)
+  int resgrad_bf16 = 1;   // ResBlock residual-gradient chain kept in bf16 (the GEMM operand copy) instead of fp32 + bf16
   int fused_encoder = 1;                                      // encoder_fused.hip half-layer kernels (0: separate launches)
   int side_wgrad = 0;
 

@@ -551,12 +551,14 @@ int SmdEngine::backward_head(hipStream_t st) {
   ln_pending_.reserve(64);
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
   const int R = rows(), B = batch_, K = nblocks();
+  // the 8-wave LayerNorm backward reads the residual gradient as bf16 (M = 2048 only)
+  const bool use_bf16_chain = resgrad_bf16 && M == 2048;
   // out_proj (models/ncsn.py:178): X = ao, dY = dpred
   RC(dense_bwd(out_proj_, W.ao, M, W.dpred, Cp_, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
   {
     LnBwdArgs b;
     b.f = ln_args(W.y[K], nullptr, R, ln_o_, params_);
-    b.dout = W.dA_M; b.dx = W.dy; b.dx_bf16 = W.dyb[K];
+    b.dout = W.dA_M; b.dx = use_bf16_chain ? nullptr : W.dy; b.dx_bf16 = W.dyb[K];
     b.dgamma = G(ln_o_.g_off); b.dbeta = G(ln_o_.b_off);
     RC(ln_bwd(b, st));
   }
@@ -580,7 +582,9 @@ int SmdEngine::backward_head(hipStream_t st) {
       b.f = ln_args(W.y[k], nullptr, R, p.ln1, params_);
       b.f.film_scale = W.ss[k]; b.f.film_shift = W.ss[k] + M; b.f.ld_film = 2 * M; b.f.rows_per_sample = S;
       b.f.swish = 1;
-      b.dout = W.dA_M; b.dres = W.dy; b.dx = W.dy; b.dx_bf16 = W.dyb[k];
+      b.dout = W.dA_M; b.dx_bf16 = W.dyb[k];
+      if (use_bf16_chain) b.dres_bf16 = W.dyb[k + 1];          // y[k+1] = y[k] + block(y[k]): dy[k] = dy[k+1] + ...
+      else { b.dres = W.dy; b.dx = W.dy; }
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 1;
       RC(ln_bwd(b, st));

@@ -138,6 +138,7 @@ struct LnBwdDev {
   LnArgs f;
   const bf16_t* dout;
   const float* dres;      // optional fp32 residual gradient added to dx (may alias dx_f32)
+  const bf16_t* dres_bf16; // or the same in bf16 (wide8 kernel only; may alias dx_bf16)
   float* dx_f32;
   bf16_t* dx_bf16;
   float* dscale;
@@ -373,6 +374,211 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_wide_kernel(LnBwdDev a) 
   }
 }
 
+// Same mathematics, laid out for memory-level parallelism.  The 4-wave kernel above runs one wave per SIMD
+// (one row group per CU at B = 256) and walks load -> compute -> store per row, so a SIMD neither computes while its
+// row loads nor loads while it computes (2 - 3.4 TB/s in the training step).  Here
+//   * 8 waves share a row group (2 per SIMD), each walks rows w, w+8, ...;
+//   * all of a row's loads (x, dy, residual gradient) are issued up front and stay raw in registers (converted at
+//     use); the per-element dh = e*scale*gamma is parked in a per-wave LDS row between the column pass and the dx
+//     pass and xhat is recomputed from raw x, so a wave needs ~150 VGPRs and the row bases live in SGPRs;
+//   * the residual gradient may be bf16 (RM = 2): the engine keeps the ResBlock residual-gradient chain in bf16.
+template <int D, bool XBF> struct WideRow {
+  typedef RowLayout<D> L;
+  float4 xf[XBF ? 1 : L::NV];
+  bf16x4_t xb[XBF ? L::NV : 1];
+  bf16x4_t dy[L::NV];
+  __device__ __forceinline__ float x(int k, int e) const {
+    if constexpr (XBF) return bf2f(xb[k][e]);
+    else return e == 0 ? xf[k].x : e == 1 ? xf[k].y : e == 2 ? xf[k].z : xf[k].w;
+  }
+};
+
+template <int D, bool XBF, int RM, bool FS, int OM>   // FS: FiLM + swish (the ResBlock norms) or neither (plain
+__global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) {   // LayerNorm); OM: 1 fp32 dx, 2 bf16, 3 both
+  typedef RowLayout<D> L;
+  constexpr int PL = L::PER_LANE, NV = L::NV, NW = 8;
+  constexpr bool film = FS, swish = FS;
+  __shared__ __attribute__((aligned(16))) float prm[4][D];      // gamma, beta, scale, shift; later the combine buffer
+  __shared__ __attribute__((aligned(16))) float park[NW][D];    // per-wave dh row
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform -> row bases live in SGPRs
+  const int grp = blockIdx.x;
+  const int r_begin = grp * a.group_rows;
+  int r_end = r_begin + a.group_rows;
+  r_end = r_end < a.f.rows ? r_end : a.f.rows;
+  {
+    const int frow = film ? (a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample) : 0;
+    const float* src[4] = {a.f.gamma, a.f.beta, film ? a.f.film_scale + (size_t)frow * a.f.ld_film : nullptr,
+                           film ? a.f.film_shift + (size_t)frow * a.f.ld_film : nullptr};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (src[q])
+        for (int c = threadIdx.x * 4; c < D; c += 2048)
+          *reinterpret_cast<float4*>(&prm[q][c]) = *reinterpret_cast<const float4*>(src[q] + c);
+  }
+  __syncthreads();
+
+  float P[PL], Q[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) P[i] = Q[i] = 0.f;
+  float* mypark = &park[w][lane * 4];
+  const uint32_t l4 = lane * 4;                     // element offset of this lane inside a 256-column chunk
+
+  auto issue = [&](int row, WideRow<D, XBF>& b) {
+    const float* xr = a.f.x + (size_t)row * D;           // uniform row bases
+    const bf16_t* xbr = a.f.x_bf16 + (size_t)row * D;
+    const bf16_t* dyr = a.dout + (size_t)row * D;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if constexpr (XBF) b.xb[k] = *reinterpret_cast<const bf16x4_t*>(xbr + (l4 + k * 256));
+      else b.xf[k] = *reinterpret_cast<const float4*>(xr + (l4 + k * 256));
+      b.dy[k] = *reinterpret_cast<const bf16x4_t*>(dyr + (l4 + k * 256));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto compute = [&](int row, const WideRow<D, XBF>& b) {
+    bf16x4_t rb[RM == 2 ? NV : 1];
+    if constexpr (RM == 2) {           // bf16 residual rows: in flight behind the whole row's arithmetic
+      const bf16_t* rr_b = a.dres_bf16 + (size_t)row * D;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) rb[k] = *reinterpret_cast<const bf16x4_t*>(rr_b + (l4 + k * 256));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // pass 1: row statistics straight from the raw registers
+    float s = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = b.x(k, e); s += v; sq += v * v; }
+    s = wave_sum(s);
+    sq = wave_sum(sq);
+    const float mean = s * (1.0f / D);
+    const float rstd = rsqrtf(sq * (1.0f / D) - mean * mean + LN_EPS);
+    // pass 2: column sums P, Q and the row sums; dh parked in LDS
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = k * 256 + lane * 4;
+      const float4 g4 = *reinterpret_cast<const float4*>(&prm[0][c]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&prm[1][c]);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      float ss[4] = {1.f, 1.f, 1.f, 1.f}, hh[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (film) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&prm[2][c]);
+        const float4 h4 = *reinterpret_cast<const float4*>(&prm[3][c]);
+        ss[0] = s4.x; ss[1] = s4.y; ss[2] = s4.z; ss[3] = s4.w;
+        hh[0] = h4.x; hh[1] = h4.y; hh[2] = h4.z; hh[3] = h4.w;
+      }
+      float dh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = k * 4 + e;
+        const float xh = (b.x(k, e) - mean) * rstd;
+        float d = bf2f(b.dy[k][e]);
+        if constexpr (swish) d *= swish_gradf_(ss[e] * (xh * gg[e] + bb[e]) + hh[e]);
+        Q[i] += d;
+        P[i] += d * xh;
+        dh[e] = d * ss[e] * gg[e];
+        s1 += dh[e];
+        s2 += dh[e] * xh;
+      }
+      *reinterpret_cast<float4*>(mypark + k * 256) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+      __builtin_amdgcn_sched_barrier(0);    // keep the LDS parameter reads of later chunks from being hoisted (VGPRs)
+    }
+    s1 = wave_sum(s1) * (1.0f / D);
+    s2 = wave_sum(s2) * (1.0f / D);
+    // pass 3: dx = rstd * (dh - mean(dh) - xhat * mean(dh * xhat)) (+ residual gradient)
+    float4 rf[RM == 1 ? NV : 1];
+    if constexpr (RM == 1) {           // fp32 residual rows: all loads first (dres may alias dx: the stores below pin them)
+      const float* rr_f = a.dres + (size_t)row * D;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) rf[k] = *reinterpret_cast<const float4*>(rr_f + (l4 + k * 256));
+    }
+    float* of = (OM & 1) ? a.dx_f32 + (size_t)row * D : nullptr;
+    bf16_t* ob = (OM & 2) ? a.dx_bf16 + (size_t)row * D : nullptr;
+    const float m2 = rstd * rstd * s2, c0 = rstd * (s1 - mean * rstd * s2);     // dx = rstd*dh - m2*x - c0
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      float rr[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (RM == 1) { rr[0] = rf[k].x; rr[1] = rf[k].y; rr[2] = rf[k].z; rr[3] = rf[k].w; }
+      if constexpr (RM == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rr[e] = bf2f(rb[k][e]);
+      }
+      const float4 d4 = *reinterpret_cast<const float4*>(mypark + k * 256);
+      const float dh[4] = {d4.x, d4.y, d4.z, d4.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (rstd * dh[e] - m2 * b.x(k, e) - c0) + rr[e];
+      if constexpr ((OM & 1) != 0) *reinterpret_cast<float4*>(of + (l4 + k * 256)) = make_float4(o[0], o[1], o[2], o[3]);
+      if constexpr ((OM & 2) != 0) {
+        bf16x4_t t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = f2bf(o[e]);
+        *reinterpret_cast<bf16x4_t*>(ob + (l4 + k * 256)) = t;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // (A register double buffer of the next row was tried: the compiler spills it at D = 2048 and waits on the spill
+  // stores, which serialises exactly what it was meant to overlap.  Two waves per SIMD already overlap one wave's
+  // loads with the other's arithmetic.)
+  for (int row = r_begin + w; row < r_end; row += NW) {
+    WideRow<D, XBF> buf;
+    issue(row, buf);
+    compute(row, buf);
+  }
+
+  // ---- combine the 8 waves' P and Q through LDS (two rounds of four, fixed order), then expand
+  constexpr int CPT = D / 512;                      // columns per thread: c = threadIdx.x + 512*j
+  float gc[CPT], bc[CPT], sc[CPT], Pc[CPT], Qc[CPT];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = threadIdx.x + 512 * j;
+    gc[j] = prm[0][c]; bc[j] = prm[1][c]; sc[j] = film ? prm[2][c] : 1.0f;
+    Pc[j] = Qc[j] = 0.f;
+  }
+#pragma unroll
+  for (int which = 0; which < 2; ++which)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();
+      if ((w >> 2) == half) {
+#pragma unroll
+        for (int i = 0; i < PL; ++i) prm[w & 3][L::col(lane, i)] = which ? Q[i] : P[i];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) {
+        const int c = threadIdx.x + 512 * j;
+        const float v = (prm[0][c] + prm[1][c]) + (prm[2][c] + prm[3][c]);
+        if (which) Qc[j] += v; else Pc[j] += v;
+      }
+    }
+  float* pg = a.partial + ((size_t)grp * 2 + 0) * D;
+  float* pb = a.partial + ((size_t)grp * 2 + 1) * D;
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int c = threadIdx.x + 512 * j;
+    pg[c] = sc[j] * Pc[j];
+    pb[c] = sc[j] * Qc[j];
+  }
+  if (film && a.dscale) {
+    const int srow = r_begin / a.f.rows_per_sample;
+    float* ds = a.dscale + (size_t)srow * a.f.ld_film;
+    float* dh = a.dshift + (size_t)srow * a.f.ld_film;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const int c = threadIdx.x + 512 * j;
+      const float vs = gc[j] * Pc[j] + bc[j] * Qc[j], vh = Qc[j];
+      ds[c] = a.dfilm_accumulate ? ds[c] + vs : vs;
+      dh[c] = a.dfilm_accumulate ? dh[c] + vh : vh;
+    }
+  }
+}
+
 // dgamma[c] += sum_g partial[g][0][c] ; dbeta likewise (fixed order -> deterministic)
 // 64 columns x 4 group-slices per block: many independent loads in flight instead of one long
 // dependent chain per column (the one-thread-per-column version was latency-bound at ~65 us).
@@ -579,6 +785,25 @@ template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(layernorm_fwd_kernel<D>, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
 }
 template <int D> static void run_bwd(const LnBwdDev& d, int ngroups, hipStream_t st) {
+  if constexpr (D == 2048) {
+    const int mode = smd_tuning_get("ln_bwd_wide");
+    const bool fs = d.f.film_scale && d.f.swish, plain = !d.f.film_scale && !d.f.swish;
+    if ((mode >= 2 || d.dres_bf16) && (fs || plain)) {
+      const int rm = d.dres_bf16 ? 2 : (d.dres ? 1 : 0);
+#define SMD_W8O(XB, RM_, FS_, OM_) \
+  hipLaunchKernelGGL((layernorm_bwd_wide8_kernel<D, XB, RM_, FS_, OM_>), dim3(ngroups), dim3(512), 0, st, d)
+#define SMD_W8F(XB, RM_, FS_) \
+  do { if (om == 3) SMD_W8O(XB, RM_, FS_, 3); else if (om == 2) SMD_W8O(XB, RM_, FS_, 2); else SMD_W8O(XB, RM_, FS_, 1); } while (0)
+#define SMD_W8(XB, RM_) do { if (fs) SMD_W8F(XB, RM_, true); else SMD_W8F(XB, RM_, false); } while (0)
+      const int om = (d.dx_f32 ? 1 : 0) | (d.dx_bf16 ? 2 : 0);
+      if (d.f.x_bf16) { if (rm == 2) SMD_W8(true, 2); else if (rm == 1) SMD_W8(true, 1); else SMD_W8(true, 0); }
+      else            { if (rm == 2) SMD_W8(false, 2); else if (rm == 1) SMD_W8(false, 1); else SMD_W8(false, 0); }
+#undef SMD_W8O
+#undef SMD_W8F
+#undef SMD_W8
+      return;
+    }
+  }
   if constexpr (D >= 1024 && D <= 2048) {      // 4096: 64 KiB of LDS parameters, keep the register kernel
     if (smd_tuning_get("ln_bwd_wide")) {
       hipLaunchKernelGGL(layernorm_bwd_wide_kernel<D>, dim3(ngroups), dim3(256), 0, st, d);
@@ -601,6 +826,9 @@ int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
   if (rc) return rc;
   SMD_ARG_CHECK(a.dout && a.partial && a.dgamma && a.dbeta, "layernorm_bwd: null dout/partial/dgamma/dbeta");
   SMD_ARG_CHECK(a.dx || a.dx_bf16, "layernorm_bwd: no dx output");
+  SMD_ARG_CHECK(!(a.dres && a.dres_bf16), "layernorm_bwd: dres and dres_bf16 are exclusive");
+  SMD_ARG_CHECK(!a.dres_bf16 || (a.f.D == 2048 && ((a.f.film_scale != nullptr) == (a.f.swish != 0))),
+                "layernorm_bwd: dres_bf16 needs D = 2048 and FiLM+swish or neither");
   const int gr = ln_group_rows(a.f);
   const int ngroups = (a.f.rows + gr - 1) / gr;
   SMD_ARG_CHECK(a.partial_elems >= (size_t)ngroups * 2 * a.f.D, "layernorm_bwd: workspace too small");
@@ -608,6 +836,7 @@ int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
   d.f = a.f;
   d.dout = a.dout;
   d.dres = a.dres;
+  d.dres_bf16 = a.dres_bf16;
   d.dx_f32 = a.dx;
   d.dx_bf16 = a.dx_bf16;
   d.dscale = a.dscale;

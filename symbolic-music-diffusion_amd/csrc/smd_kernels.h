@@ -108,6 +108,7 @@ struct LnBwdArgs {
   LnArgs f;                          // the forward arguments (x, gamma, beta, film, swish); f.out unused
   const bf16_t* dout = nullptr;
   const float* dres = nullptr;
+  const bf16_t* dres_bf16 = nullptr;  // bf16 residual gradient instead of dres (D in {1024, 2048})
   float* dx = nullptr;
   bf16_t* dx_bf16 = nullptr;
   float* dgamma = nullptr;

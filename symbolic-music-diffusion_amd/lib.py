@@ -90,6 +90,9 @@ _SIGS = {
                                     C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_void]),
     "smd_layernorm_bwd_ex": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
                                        c_void, c_void, c_i64, c_void]),
+    "smd_layernorm_bwd_film": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int,
+                                         C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
+                                         C.c_int, c_void, c_i64, c_void]),
     "smd_attention_fwd": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "smd_attention_bwd": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "smd_noise_embed": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),

@@ -388,6 +388,68 @@ def test_layernorm_fwd_bwd(L, dev, D, film, swish):
         assert rel(dss, ssr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("wide", [2, 1])
+@pytest.mark.parametrize("fs", [True, False])
+@pytest.mark.parametrize("xbf,res,om", [(False, "bf16", 2), (True, None, 2), (False, None, 2), (False, "f32", 3),
+                                        (False, None, 1), (True, "f32", 1), (True, "bf16", 3)])
+def test_layernorm_bwd_film_forms(L, dev, xbf, res, om, fs, wide):
+    """The engine's ResBlock forms of the LayerNorm backward (smd_layernorm_bwd_film): bf16 / fp32 input, residual
+    gradient none / fp32 in place / bf16, fp32 and/or bf16 dx, accumulate into dscale/dshift; the 8-wave kernel
+    (tuning ln_bwd_wide = 2) and the 4-wave one (1; takes a bf16 residual gradient through the 8-wave kernel)."""
+    import smd_amd.lib as lib
+    D, rows, rps = 2048, 160, 32                     # 5 row groups of 32 rows
+    g = torch.Generator().manual_seed(11 + xbf + 2 * om)
+    x = torch.randn(rows, D, generator=g) * 1.3 - 0.2
+    if xbf:
+        x = bf(x).float()
+    gamma, beta = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    ns = rows // rps
+    ss = torch.cat([1 + 0.3 * torch.randn(ns, D, generator=g), 0.2 * torch.randn(ns, D, generator=g)], dim=1)
+    dout = bf(torch.randn(rows, D, generator=g))
+    dres = torch.randn(rows, D, generator=g)
+    if res == "bf16":
+        dres = bf(dres).float()
+    dss0 = torch.randn(ns, 2 * D, generator=g)
+
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ssr = ss.double().requires_grad_(True)
+    y = O.layer_norm(xr, {"n.scale": gr, "n.bias": br}, "n")
+    if fs:
+        y = O.swish(ssr[:, :D].repeat_interleave(rps, 0) * y + ssr[:, D:].repeat_interleave(rps, 0))
+    y.backward(dout.double())
+    want_dx = xr.grad + (dres.double() if res else 0.0)
+
+    lib.check(L.smd_set_tuning(b"ln_bwd_wide", wide))
+    try:
+        xd = (bf(x) if xbf else x).to(dev)
+        gd, bd, ssd = gamma.to(dev), beta.to(dev), ss.contiguous().to(dev)
+        dx32 = dres.to(dev).clone() if res == "f32" else torch.zeros(rows, D, device=dev)     # in place when fp32
+        dresb = bf(dres).to(dev) if res == "bf16" else None
+        dxb = torch.zeros(rows, D, dtype=torch.bfloat16, device=dev)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        dss = dss0.to(dev).clone()
+        partial = torch.zeros(rows * 2 * D, device=dev)
+        doutd = dout.to(dev)
+        ck(L, L.smd_layernorm_bwd_film(None if xbf else P(xd), P(xd) if xbf else None, rows, D, P(gd), P(bd),
+                                       P(ssd) if fs else None, P(ssd[:, D:]) if fs else None, 2 * D, rps, int(fs),
+                                       P(doutd), P(dx32) if res == "f32" else None, P(dresb),
+                                       P(dx32) if om & 1 else None, P(dxb) if om & 2 else None, P(dg), P(db),
+                                       P(dss) if fs else None, P(dss[:, D:]) if fs else None, 1,
+                                       P(partial), partial.numel(), st()))
+        torch.cuda.synchronize()
+    finally:
+        lib.check(L.smd_set_tuning(b"ln_bwd_wide", 2))
+    if om & 1:
+        assert rel(dx32, want_dx) < 1e-4
+    if om & 2:
+        assert rel(dxb.float(), want_dx) < 4e-3              # bf16 output rounding
+    assert rel(dg, gr.grad) < 1e-4
+    assert rel(db, br.grad) < 1e-4
+    if fs:
+        assert rel(dss, dss0.double() + ssr.grad) < 1e-4     # dfilm_accumulate = 1
+
+
 @pytest.mark.parametrize("H", [8, 16, 4])
 def test_attention_fwd_bwd(L, dev, H):
     B, S, E = 5, 32, 128

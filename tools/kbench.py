@@ -97,30 +97,39 @@ def main():
         lib.check(L.smd_set_tuning(b"gemm_nt_deep", 1))
         return
     if a.ln_ab:
-        for D, film, xb in ((2048, 0, 0), (2048, 1, 0), (2048, 1, 1), (1024, 1, 0)):
-            x = torch.randn(R, D, device=dev)
-            xbf = x.to(torch.bfloat16)
-            g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
-            ss = torch.randn(R // 32, 2 * D, device=dev)
-            dout = bf(R, D)
-            dx = torch.empty(R, D, device=dev)
-            dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
-            dss = torch.zeros(R // 32, 2 * D, device=dev)
-            part = torch.empty(R * 2 * D // 16, device=dev)
-            # C-ABI form: fp32 x, fp32 dx out (the engine's ln1 also reads dres and writes bf16: more traffic)
-            f = lambda: lib.check(L.smd_layernorm_bwd(x.data_ptr(), R, D, g.data_ptr(), b.data_ptr(),
-                                                      ss.data_ptr() if film else None, ss[:, D:].data_ptr() if film else None,
-                                                      2 * D, 32, film, dout.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                                      dss.data_ptr() if film else None, dss[:, D:].data_ptr() if film else None,
-                                                      part.data_ptr(), part.numel(), st))
-            res = {0: [], 1: []}
+        # the engine's forms of the D = 2048 LayerNorm backward: (name, x bf16, residual gradient, outputs, FiLM+swish)
+        D = 2048
+        forms = [("res.ln2  (bf16 x, bf16 dx)", 1, None, 2, 1),
+                 ("res.ln1  (f32 x, f32 dres in place, f32+bf16 dx)", 0, "f32", 3, 1),
+                 ("res.ln1  (f32 x, bf16 dres, bf16 dx)", 0, "bf16", 2, 1),
+                 ("ln_o     (f32 x, f32+bf16 dx)", 0, None, 3, 0),
+                 ("ln_o     (f32 x, bf16 dx)", 0, None, 2, 0)]
+        x = torch.randn(R, D, device=dev)
+        xbf = x.to(torch.bfloat16)
+        g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+        ss = torch.randn(R // 32, 2 * D, device=dev)
+        dout, dresb = bf(R, D), bf(R, D)
+        dx, dxb = torch.zeros(R, D, device=dev), torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+        dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        dss = torch.zeros(R // 32, 2 * D, device=dev)
+        part = torch.empty(R * 2 * D // 16, device=dev)
+        for name, xb, res, om, fs in forms:
+            nbytes = R * D * ((2 if xb else 4) + 2 + {None: 0, "f32": 4, "bf16": 2}[res] + (4 if om & 1 else 0) + (2 if om & 2 else 0))
+            f = lambda: lib.check(L.smd_layernorm_bwd_film(
+                None if xb else x.data_ptr(), xbf.data_ptr() if xb else None, R, D, g.data_ptr(), b.data_ptr(),
+                ss.data_ptr() if fs else None, ss[:, D:].data_ptr() if fs else None, 2 * D, 32, fs, dout.data_ptr(),
+                dx.data_ptr() if res == "f32" else None, dresb.data_ptr() if res == "bf16" else None,
+                dx.data_ptr() if om & 1 else None, dxb.data_ptr() if om & 2 else None, dg.data_ptr(), db.data_ptr(),
+                dss.data_ptr() if fs else None, dss[:, D:].data_ptr() if fs else None, 0, part.data_ptr(), part.numel(), st))
+            modes = (2,) if res == "bf16" else (1, 2)
+            out = {m: [] for m in modes}
             for _ in range(5):
-                for mode in (0, 1):
-                    lib.check(L.smd_set_tuning(b"ln_bwd_wide", mode))
-                    res[mode].append(timeit(f, a.reps))
-            for mode in (0, 1):
-                rec(f"ln_ab:{'wide' if mode else 'regs'}(film={film}) +reduce", [R, D], sorted(res[mode])[2], bytes_=R * D * 10.0)
-        lib.check(L.smd_set_tuning(b"ln_bwd_wide", 1))
+                for m in modes:
+                    lib.check(L.smd_set_tuning(b"ln_bwd_wide", m))
+                    out[m].append(timeit(f, a.reps))
+            for m in modes:
+                rec(f"ln_bwd[{'8-wave' if m == 2 else '4-wave'}] {name} +reduce", [R, D], sorted(out[m])[2], bytes_=float(nbytes))
+        lib.check(L.smd_set_tuning(b"ln_bwd_wide", 2))
         return
     if a.tn128:
         lib.check(L.smd_set_tuning(b"gemm_tn256", 0))
