@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--tuning", action="append", default=[], help="process-wide kernel knob key=value (smd_set_tuning)")
     ap.add_argument("--engine-opt", action="append", default=[], help="extra engine option key=value (A/B runs)")
     ap.add_argument("--group-wgrad", type=int, default=2, help="128-wide wgrads: 2 grouped per encoder layer, 1 grouped at the end, 0 one launch each")
+    ap.add_argument("--rng-impl", choices=["philox", "threefry"], default="philox",
+                    help="noise streams: in-kernel Philox (default) or jax.random-compatible threefry2x32 draws")
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
     return ap.parse_args()
 
@@ -146,7 +148,7 @@ def main():
     for kv in a.engine_opt:
         k, _, v = kv.partition("=")
         opt.engine.set_option(k, int(v))
-    key = N.PRNGKey(0)
+    key = N.make_key(0, a.rng_impl)
 
     def one_train():
         train_step(N.diffusion_loss, x0, opt, betas, key, 1e-3, grad_clip=1.0, comm=comm, lr_gamma=0.98,
@@ -167,12 +169,23 @@ def main():
     io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B
     io.metrics_partial, io.collection, io.slot_table = metrics_partial.data_ptr(), collection.data_ptr(), eng.slot_table.data_ptr()
     graph = None
+    if a.rng_impl == "threefry":          # the reference's per-iteration noise keys, normals drawn by the threefry kernel
+        import smd_amd.jax_random as J
+        _ik, nk = J.sampler_key_tables(N.make_key(7, "threefry"), 1000)
+        nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
+        zbuf = torch.zeros_like(x)
+        io.z_in = zbuf.data_ptr()
+
+    def sample_step():
+        if a.rng_impl == "threefry":
+            J.fill_normal_from_table(zbuf, nk_d, t_ptr, 1000, n_total=world * B * 32 * 512, offset=rank * B * 32 * 512)
+        eng.sample_step(io)
 
     def one_sample():
         if graph is not None:
             graph.replay()
         else:
-            eng.sample_step(io)
+            sample_step()
 
     do_train, do_sample = a.mode in ("both", "train"), a.mode in ("both", "sample")
     log(f"rank {rank}: model + buffers ready, warming up")
@@ -187,11 +200,11 @@ def main():
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            eng.sample_step(io)
+            sample_step()
         torch.cuda.current_stream().wait_stream(s)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            eng.sample_step(io)
+            sample_step()
         one_sample()
     t_ptr.fill_(999)
 
@@ -279,7 +292,7 @@ def main():
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,
-                       "sample_step": "eager" if a.no_graph else "hipGraph replay"},
+                       "sample_step": "eager" if a.no_graph else "hipGraph replay", "rng": a.rng_impl},
             "train_steps_per_sec": round(world * a.steps / t_train, 3) if do_train else None,
             "sample_steps_per_sec": round(world * a.steps / t_sample, 3) if do_sample else None,
             "seq_steps_per_sec": round(world * n_eval * B / total, 1),

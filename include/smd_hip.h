@@ -184,6 +184,19 @@ int smd_noise_embed(const float* noise_level, int n, int channels, smd_bf16* out
 /* Philox4x32-10 normals: out[b][e], counter (e/4, b + sample_offset, stream_id, 0) */
 int smd_rng_normal(float* out, int B, int per_sample, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
                    uint32_t sample_offset, void* stream);
+/* jax.random-compatible draws (jax 0.2.8 threefry2x32 conventions; replaces jax.random.{randint,uniform,normal} at
+ * utils/losses.py:272-294, utils/ebm_utils.py:343-345,361-362, train_ncsn.py:539-540).  Each call fills the window
+ * [offset, offset+count) of a logical array of n_total <= 2^32 elements with exactly the values
+ * jax.random.X(key=(k0,k1), shape=(n_total,)) holds there, so sharded callers reproduce the single-process stream.
+ * smd_threefry_normal: key_table != NULL takes the key from key_table[idx_add + idx_mul * *idx_ptr] on device
+ * (uint32 pairs), which keeps a captured reverse-sampling step replayable. */
+int smd_threefry_bits(uint32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1, void* stream);
+int smd_threefry_uniform(float* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                         float minval, float maxval, void* stream);
+int smd_threefry_normal(float* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                        const uint32_t* key_table, const int32_t* idx_ptr, int idx_mul, int idx_add, void* stream);
+int smd_threefry_randint(int32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                         int32_t minval, int32_t maxval, void* stream);
 int smd_cast_pad_bf16(const float* in, int rows, int cols, smd_bf16* out, int ld_out, void* stream);
 /* one reverse step on explicit eps_hat (the elementwise part of utils/ebm_utils.py:327-394) */
 int smd_ddpm_reverse_step(float* x, const float* eps_hat, int B, int S, int C, const float* coef,

@@ -598,3 +598,135 @@ def philox_normal4(ctr: np.ndarray, key: np.ndarray) -> np.ndarray:
     a0 = 2.0 * np.pi * u[..., 1]
     a1 = 2.0 * np.pi * u[..., 3]
     return np.stack([r0 * np.cos(a0), r0 * np.sin(a0), r1 * np.cos(a1), r1 * np.sin(a1)], axis=-1)
+
+
+# ----------------------------------------------------------------------------------
+# jax.random (jax 0.2.8) restated: threefry2x32 counter PRNG and the split / bits / uniform /
+# normal / randint conventions the reference consumes at utils/losses.py:271-294,
+# utils/ebm_utils.py:329,342-345,360-362 and train_ncsn.py:318-319,358,536-540.
+#
+# PINNED against published known answers (tests/golden/jax_random_kat.json): the Random123
+# threefry2x32-20 vectors, and the key / normal values printed in JAX's own documentation
+# ("JAX - The Sharp Bits", section "JAX PRNG"): PRNGKey(0) -> split -> keys, and
+# random.normal(key, (1,)) for six keys.  They fix: the key schedule and rotations, the
+# "counter halves" layout of random_bits (incl. the odd-size zero pad), split's reshape, the
+# mantissa-fill uniform with its max(minval, .) clamp, and XLA's float32 erf_inv polynomial.
+# randint's two-draw multiplier scheme has no published vector: restated from memory (unpinned).
+# ----------------------------------------------------------------------------------
+_TF_ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
+
+
+def threefry2x32(key, x0, x1):
+    """Threefry-2x32, 20 rounds (Random123).  key = (k0, k1); x0/x1 uint32 arrays -> (y0, y1)."""
+    k0, k1 = np.uint32(key[0]), np.uint32(key[1])
+    ks = (k0, k1, np.uint32(k0 ^ k1 ^ np.uint32(0x1BD11BDA)))
+    x0 = np.asarray(x0, dtype=np.uint32).copy()
+    x1 = np.asarray(x1, dtype=np.uint32).copy()
+    with np.errstate(over="ignore"):
+        x0 = x0 + ks[0]
+        x1 = x1 + ks[1]
+        for i in range(5):
+            for r in _TF_ROT[i % 2]:
+                x0 = x0 + x1
+                x1 = ((x1 << np.uint32(r)) | (x1 >> np.uint32(32 - r))) ^ x0
+            x0 = x0 + ks[(i + 1) % 3]
+            x1 = x1 + ks[(i + 2) % 3] + np.uint32(i + 1)
+    return x0, x1
+
+
+def jax_prngkey(seed: int):
+    """jax.random.PRNGKey with 32-bit ints (x64 disabled): [0, seed mod 2^32]."""
+    return (np.uint32(0), np.uint32(int(seed) & 0xFFFFFFFF))
+
+
+def jax_random_bits(key, n: int) -> np.ndarray:
+    """_random_bits(key, 32, shape) flattened: threefry_2x32(key, iota(n)) where the counter vector is split
+    into two halves (x0 = first half, x1 = second half, odd n padded with one zero) and the two output words
+    are concatenated again."""
+    h = (n + 1) // 2
+    cnt = np.arange(2 * h, dtype=np.uint32)
+    if n % 2:
+        cnt[-1] = 0
+    y0, y1 = threefry2x32(key, cnt[:h], cnt[h:])
+    return np.concatenate([y0, y1])[:n]
+
+
+def jax_split(key, num: int = 2):
+    """jax.random.split: random_bits over 2*num counters reshaped (num, 2)."""
+    b = jax_random_bits(key, 2 * num).reshape(num, 2)
+    return [(b[j, 0], b[j, 1]) for j in range(num)]
+
+
+def jax_uniform(key, n: int, minval=0.0, maxval=1.0) -> np.ndarray:
+    """jax.random.uniform (float32): mantissa fill -> [1,2) - 1 -> * (maxval - minval) + minval -> max(minval, .).
+    minval / maxval may be per-element arrays (utils/losses.py:283-286)."""
+    f = np.float32
+    bits = jax_random_bits(key, n)
+    u01 = ((bits >> np.uint32(9)) | np.uint32(0x3F800000)).view(np.float32) - f(1.0)
+    lo = np.asarray(minval, dtype=np.float32)
+    hi = np.asarray(maxval, dtype=np.float32)
+    return np.maximum(lo, (u01 * (hi - lo)).astype(np.float32) + lo).astype(np.float32)
+
+
+_ERFINV_LT5 = (2.81022636e-08, 3.43273939e-07, -3.5233877e-06, -4.39150654e-06, 0.00021858087,
+               -0.00125372503, -0.00417768164, 0.246640727, 1.50140941)
+_ERFINV_GE5 = (-0.000200214257, 0.000100950558, 0.00134934322, -0.00367342844, 0.00573950773,
+               -0.0076224613, 0.00943887047, 1.00167406, 2.83297682)
+
+
+def erfinv_f32(x: np.ndarray) -> np.ndarray:
+    """XLA's float32 erf_inv (Giles' single-precision polynomial), evaluated in float32 like XLA does."""
+    f = np.float32
+    x = np.asarray(x, dtype=np.float32)
+    w = -np.log(((f(1) - x) * (f(1) + x)).astype(np.float32)).astype(np.float32)
+    lt = w < f(5)
+    ww = np.where(lt, w - f(2.5), np.sqrt(np.maximum(w, f(0))).astype(np.float32) - f(3)).astype(np.float32)
+    p = np.where(lt, f(_ERFINV_LT5[0]), f(_ERFINV_GE5[0])).astype(np.float32)
+    for a, b in zip(_ERFINV_LT5[1:], _ERFINV_GE5[1:]):
+        p = (np.where(lt, f(a), f(b)) + (p * ww).astype(np.float32)).astype(np.float32)
+    return (p * x).astype(np.float32)
+
+
+def jax_normal(key, n: int) -> np.ndarray:
+    """jax.random.normal (float32): sqrt(2) * erf_inv(uniform(key, minval=nextafter(-1, 0), maxval=1))."""
+    lo = np.nextafter(np.float32(-1), np.float32(0), dtype=np.float32)
+    u = jax_uniform(key, n, lo, np.float32(1))
+    return (np.float32(np.sqrt(2)) * erfinv_f32(u)).astype(np.float32)
+
+
+def jax_randint(key, n: int, minval: int, maxval: int) -> np.ndarray:
+    """jax.random.randint (int32), jax 0.2.8: two 32-bit draws from split(key); span = maxval - minval (1 if
+    maxval <= minval); multiplier = (2^16 % span)^2 % span; ((hi % span) * multiplier + lo % span) % span."""
+    k1, k2 = jax_split(key)
+    hi, lo = jax_random_bits(k1, n), jax_random_bits(k2, n)
+    maxval = max(minval + 1, maxval)
+    span = np.uint32(maxval - minval)
+    with np.errstate(over="ignore"):
+        mult = np.uint32(np.uint32(1 << 16) % span)
+        mult = np.uint32(np.uint32(mult * mult) % span)
+        off = ((hi % span) * mult + (lo % span)) % span
+    return (np.int32(minval) + off.astype(np.int32)).astype(np.int32)
+
+
+def jax_diffusion_loss_draws(rng, batch_shape, T: int, continuous_noise: bool = True):
+    """The draws of utils/losses.py:271-294 for key ``rng``: (labels int32 (B,), eps float32 batch_shape).
+    The uniform of :283-286 is degenerate (minval > maxval -> minval) and needs no bits."""
+    _rng, label_rng, sample_rng = jax_split(rng, 3)
+    B = int(batch_shape[0])
+    labels = jax_randint(label_rng, B, int(continuous_noise), T + int(continuous_noise))
+    eps = jax_normal(sample_rng, int(np.prod(batch_shape))).reshape(batch_shape)
+    return labels, eps
+
+
+def jax_sampler_keys(ld_rng, T: int):
+    """Per-iteration keys of utils/ebm_utils.py:329,342,360 walking t = T-1 .. 0:
+    returns (infill_keys, noise_keys), each a list indexed by ITERATION (0 = first step, t = T-1)."""
+    rng = ld_rng
+    infill_keys, noise_keys = [], []
+    for _ in range(T):
+        rng, _key = jax_split(rng)
+        rng, infill_rng = jax_split(rng)
+        rng, noise_rng = jax_split(rng)
+        infill_keys.append(infill_rng)
+        noise_keys.append(noise_rng)
+    return infill_keys, noise_keys

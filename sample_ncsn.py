@@ -35,7 +35,7 @@ def load_model(FLAGS, shape, device):
     from smd_amd import checkpoint, ncsn
     model_kwargs = dict(num_layers=FLAGS.num_layers, num_heads=FLAGS.num_heads,
                         num_mlp_layers=FLAGS.num_mlp_layers, mlp_dims=FLAGS.mlp_dims)
-    rng = ncsn.PRNGKey(FLAGS.sample_seed)
+    rng = ncsn.make_key(FLAGS.sample_seed, FLAGS.rng_impl)
     rng, model_rng = ncsn.split(rng)
     model = ncsn.create_model(model_rng, shape, model_kwargs, batch_size=1, verbose=True,
                               architecture=FLAGS.architecture, num_timesteps=FLAGS.num_sigmas, device=device)
@@ -46,7 +46,7 @@ def load_model(FLAGS, shape, device):
     return model, rng
 
 
-def generate_samples(FLAGS, model, rng, sample_shape, num_samples, sigmas, sample_offset=0):
+def generate_samples(FLAGS, model, rng, sample_shape, num_samples, sigmas, sample_offset=0, global_num_samples=None):
     """sample_ncsn.py:313-365."""
     from smd_amd import ncsn
     rng, sample_rng = ncsn.split(rng)
@@ -54,31 +54,45 @@ def generate_samples(FLAGS, model, rng, sample_shape, num_samples, sigmas, sampl
     generated, collection, ld_metrics = ncsn.sample(
         model, sigmas, sample_rng, sample_shape, num_samples=num_samples, sampling=FLAGS.sampling,
         epsilon=FLAGS.ld_epsilon, steps=FLAGS.ld_steps, denoise=FLAGS.denoise, sample_offset=sample_offset,
-        use_graph=FLAGS.graph)
+        use_graph=FLAGS.graph, global_num_samples=global_num_samples)
     torch.cuda.synchronize()
     log.info("Generated samples in %f seconds", time.time() - t0)
     return generated, collection, ld_metrics
 
 
-def infill_samples(FLAGS, model, rng, samples, masks, sigmas):
-    """sample_ncsn.py:189-242 (init ~ U[0,1) like :228; here Philox uniform via torch on the device)."""
-    from smd_amd import ncsn
+def infill_samples(FLAGS, model, rng, samples, masks, sigmas, sample_offset=0, global_num_samples=None):
+    """sample_ncsn.py:189-242 (init ~ U[0,1) like :228: jax.random.uniform with --rng_impl=threefry, torch's device
+    generator otherwise)."""
+    from smd_amd import jax_random, ncsn
     init_rng, ld_rng = ncsn.split(rng)
-    g = torch.Generator(device=model.engine.device).manual_seed(init_rng.seed & 0x7FFFFFFFFFFFFFFF)
-    init = torch.rand(samples.shape, generator=g, device=model.engine.device)
+    if isinstance(init_rng, jax_random.ThreefryKey):
+        per = int(np.prod(samples.shape[1:]))
+        n_glob = (global_num_samples or (len(samples) + sample_offset)) * per
+        init = jax_random.uniform(init_rng, samples.shape, model.engine.device, n_total=n_glob, offset=sample_offset * per)
+    else:
+        g = torch.Generator(device=model.engine.device).manual_seed(init_rng.seed & 0x7FFFFFFFFFFFFFFF)
+        init = torch.rand(samples.shape, generator=g, device=model.engine.device)
     generated, collection, ld_metrics = ncsn.diffusion_dynamics(
         ld_rng, model, sigmas, init, FLAGS.ld_epsilon, FLAGS.ld_steps, FLAGS.denoise, True,
-        infill_samples=samples, infill_masks=masks, use_graph=FLAGS.graph)
+        infill_samples=samples, infill_masks=masks, use_graph=FLAGS.graph, sample_offset=sample_offset,
+        global_num_samples=global_num_samples)
     return generated, collection, ncsn.collate_sampling_metrics(ld_metrics.cpu().numpy())
 
 
-def diffusion_stochastic_encoder(samples, sigmas, rng):
+def diffusion_stochastic_encoder(samples, sigmas, rng, device="cuda:0", sample_offset=0, global_num_samples=None):
     """sample_ncsn.py:245-266: z = sqrt(ap[T]) x + sqrt(1-ap[T]) noise.  alphas_prod[T] is one past
-    the end upstream; JAX clamps the gather, i.e. it uses ap[T-1] (SURVEY quirks ledger)."""
+    the end upstream; JAX clamps the gather, i.e. it uses ap[T-1] (SURVEY quirks ledger).  ``rng`` is the first
+    child of split(PRNGKey(seed)) -- the reference draws the noise from it, not from noise_rng (:262-263)."""
+    from smd_amd import jax_random
     ap = schedule.alphas_cumprod(sigmas)
     a_T = float(ap[-1])
-    g = torch.Generator().manual_seed(rng.seed & 0x7FFFFFFFFFFFFFFF)
-    noise = torch.randn(samples.shape, generator=g).numpy()
+    if isinstance(rng, jax_random.ThreefryKey):
+        per = int(np.prod(samples.shape[1:]))
+        n_glob = (global_num_samples or (len(samples) + sample_offset)) * per
+        noise = jax_random.normal(rng, samples.shape, device, n_total=n_glob, offset=sample_offset * per).cpu().numpy()
+    else:
+        g = torch.Generator().manual_seed(rng.seed & 0x7FFFFFFFFFFFFFFF)
+        noise = torch.randn(samples.shape, generator=g).numpy()
     return np.sqrt(a_T) * samples + np.sqrt(1 - a_T) * noise
 
 
@@ -132,23 +146,25 @@ def main(argv):
             fixed_idx, infilled_idx = idx[:8] + idx[-8:], idx[8:-8]
             samples[:, infilled_idx, :] = 0
             masks[:, fixed_idx, :] = 1
-        generated, collection, ld_metrics = infill_samples(FLAGS, model, rng, samples, masks, sigmas)
+        generated, collection, ld_metrics = infill_samples(FLAGS, model, rng, samples, masks, sigmas, sample_offset=lo,
+                                                           global_num_samples=num)
     elif FLAGS.interpolate:                                                 # :425-435
         starts = real[lo:hi]
         goals = np.roll(real, shift=1, axis=0)[lo:hi]
-        zs, zg = (diffusion_stochastic_encoder(v, sigmas, rng) for v in (starts, goals))
-        _, ld_rng, _ = ncsn.split(rng, num=3)
+        zs, zg = (diffusion_stochastic_encoder(v, sigmas, rng, dev, lo, num) for v in (starts, goals))
+        _, ld_rng, _ = ncsn.split(ncsn.make_key(FLAGS.sample_seed, FLAGS.rng_impl), num=3)     # :271-272 (the root key)
         gens, colls = [], []
         for i, alpha in enumerate(np.linspace(0.0, 1.0, 9)):
             g, c, ld = ncsn.diffusion_dynamics(ld_rng, model, sigmas, ((1 - alpha) * zs + alpha * zg).astype(np.float32),
-                                               use_graph=FLAGS.graph, sample_offset=lo)
+                                               use_graph=FLAGS.graph, sample_offset=lo, global_num_samples=num)
             gens.append(g.cpu().numpy())
             colls.append(c.cpu().numpy())
             log.info("Generated samples %i out of %i", i, 9)
         generated, collection = np.stack(gens), np.stack(colls)
         ld_metrics = ncsn.collate_sampling_metrics(ld.cpu().numpy())
     else:                                                                   # :437-439
-        generated, collection, ld_metrics = generate_samples(FLAGS, model, rng, shape, hi - lo, sigmas, sample_offset=lo)
+        generated, collection, ld_metrics = generate_samples(FLAGS, model, rng, shape, hi - lo, sigmas, sample_offset=lo,
+                                                             global_num_samples=num)
 
     generated = generated.cpu().numpy() if torch.is_tensor(generated) else generated
     collection = collection.cpu().numpy() if torch.is_tensor(collection) else collection

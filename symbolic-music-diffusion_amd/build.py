@@ -14,16 +14,18 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "attention.hip", "encoder_fused.hip", "diffusion.hip", "optim.hip",
+SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "attention.hip", "encoder_fused.hip", "diffusion.hip", "rng_jax.hip", "optim.hip",
            "engine.hip", "capi.hip"]
-HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h",
+HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h", "rng_threefry.h",
            os.path.join("..", "..", "include", "smd_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
 # per-file code generation switches
-EXTRA_FLAGS = {"encoder_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA_FLAGS = {"encoder_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+               # jax.random streams: every mul/add rounds separately (HIP's __fmul_rn/__fadd_rn are plain operators)
+               "rng_jax.hip": ["-ffp-contract=off"]}
 
 
 def find_hipcc() -> str:

@@ -236,6 +236,21 @@ int smd_noise_embed(const float* s, int n, int channels, smd_bf16* out, int ld_o
 int smd_rng_normal(float* out, int Bn, int per_sample, uint32_t lo, uint32_t hi, uint32_t stream_id, uint32_t off, void* stream) {
   return launch_fill_normal(out, Bn, per_sample, RngKey{lo, hi}, stream_id, off, S(stream));
 }
+int smd_threefry_bits(uint32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1, void* stream) {
+  return launch_threefry_bits(out, n_total, offset, count, k0, k1, S(stream));
+}
+int smd_threefry_uniform(float* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1, float minval,
+                         float maxval, void* stream) {
+  return launch_threefry_uniform(out, n_total, offset, count, k0, k1, minval, maxval, S(stream));
+}
+int smd_threefry_normal(float* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                        const uint32_t* key_table, const int32_t* idx_ptr, int idx_mul, int idx_add, void* stream) {
+  return launch_threefry_normal(out, n_total, offset, count, k0, k1, key_table, idx_ptr, idx_mul, idx_add, S(stream));
+}
+int smd_threefry_randint(int32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                         int32_t minval, int32_t maxval, void* stream) {
+  return launch_threefry_randint(out, n_total, offset, count, k0, k1, minval, maxval, S(stream));
+}
 int smd_cast_pad_bf16(const float* in, int rows, int cols, smd_bf16* out, int ld_out, void* stream) {
   return launch_cast_pad_bf16(in, rows, cols, B(out), ld_out, S(stream));
 }

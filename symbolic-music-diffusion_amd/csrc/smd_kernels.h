@@ -204,6 +204,19 @@ int launch_cast_pad_bf16(const float* in, int rows, int cols, bf16_t* out, int l
 int launch_fill_normal(float* out, int B, int per_sample, RngKey key, uint32_t stream,
                        uint32_t sample_offset, hipStream_t st);
 
+// ------------------------------------------------------------------ jax.random-compatible draws (rng_jax.hip)
+// window [offset, offset+count) of a logical n_total-element array (n_total <= 2^32); values identical to
+// jax.random.{bits,uniform,normal,randint}(key, (n_total,)) of jax 0.2.8 -- see rng_threefry.h
+int launch_threefry_bits(uint32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                         hipStream_t st);
+int launch_threefry_uniform(float* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                            float minval, float maxval, hipStream_t st);
+// key_table != null: key = key_table[idx_add + idx_mul * *idx_ptr] (read on device: graph-replayable)
+int launch_threefry_normal(float* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                           const uint32_t* key_table, const int32_t* idx_ptr, int idx_mul, int idx_add, hipStream_t st);
+int launch_threefry_randint(int32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
+                            int32_t minval, int32_t maxval, hipStream_t st);
+
 // ------------------------------------------------------------------ optimiser (optim.hip)
 struct AdamArgs {
   float* params = nullptr;            // fp32 master [n]

@@ -96,6 +96,10 @@ _SIGS = {
     "smd_attention_fwd": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "smd_attention_bwd": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void]),
     "smd_noise_embed": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
+    "smd_threefry_bits": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, c_void]),
+    "smd_threefry_uniform": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, C.c_float, C.c_float, c_void]),
+    "smd_threefry_normal": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, c_void, c_void, C.c_int, C.c_int, c_void]),
+    "smd_threefry_randint": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, C.c_int32, C.c_int32, c_void]),
     "smd_rng_normal": (C.c_int, [c_void, C.c_int, C.c_int, c_u32, c_u32, c_u32, c_u32, c_void]),
     "smd_cast_pad_bf16": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
     "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_u32,

@@ -19,9 +19,11 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from . import jax_random as _jr
 from . import lib as _lib
 from . import schedule as _sched
 from .engine import ARCH_IDS, Engine, NetConfig
+from .jax_random import ThreefryKey
 
 COLLECTION_STEPS = _sched.COLLECTION_STEPS
 
@@ -29,8 +31,9 @@ COLLECTION_STEPS = _sched.COLLECTION_STEPS
 # ------------------------------------------------------------------ rng keys
 @dataclass(frozen=True)
 class PRNGKey:
-    """Stand-in for jax.random.PRNGKey: a 64-bit seed for the engine's Philox streams.
-    (Bit-compatible threefry streams are a "next" row; parity tests pass draws explicitly.)"""
+    """A 64-bit seed for the engine's own Philox streams (throughput mode: draws happen inside the fused kernels).
+    ``jax_random.PRNGKey(seed)`` makes a ``ThreefryKey`` instead; every function below that takes ``rng`` then
+    consumes the reference's jax.random streams bit for bit (--rng_impl=threefry on the CLIs)."""
     seed: int
 
     def __post_init__(self):
@@ -45,8 +48,20 @@ def _splitmix64(x: int) -> int:
     return z ^ (z >> 31)
 
 
-def split(key: PRNGKey, num: int = 2) -> Tuple[PRNGKey, ...]:
-    """jax.random.split look-alike (train_ncsn.py:318-319,358): ``num`` independent child keys."""
+def make_key(seed: int, impl: str = "philox"):
+    """PRNGKey(seed) of the chosen implementation: 'philox' (engine streams) or 'threefry' (jax.random streams)."""
+    if impl == "threefry":
+        return _jr.PRNGKey(seed)
+    if impl != "philox":
+        raise ValueError(f"rng_impl must be 'philox' or 'threefry', got {impl!r}")
+    return PRNGKey(seed)
+
+
+def split(key, num: int = 2):
+    """jax.random.split (train_ncsn.py:318-319,358): exact for a ThreefryKey, ``num`` independent child seeds for
+    the engine's Philox keys."""
+    if isinstance(key, ThreefryKey):
+        return _jr.split(key, num)
     return tuple(PRNGKey(_splitmix64(key.seed ^ _splitmix64(i + 1))) for i in range(num))
 
 
@@ -159,6 +174,8 @@ def diffusion_loss(batch, model: Model, betas, rng: PRNGKey, continuous_noise=Fa
     eng.bind(batch.shape[0], training=True)
     lab = None if labels is None else torch.as_tensor(labels).to(eng.device, torch.int32).contiguous()
     e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
+    if isinstance(rng, ThreefryKey) and lab is None and e is None:
+        lab, e = _jr.diffusion_loss_draws(rng, tuple(batch.shape), len(betas), eng.device)      # :271-294
     eng.loss_backward(batch, lab, e, seed=rng.seed, stage=3)
     loss = eng.loss_per_sample().clone()
     assert loss.shape == batch.shape[:1]                                          # utils/losses.py:306
@@ -181,14 +198,17 @@ def collate_sampling_metrics(ld_metrics):
 def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=None, denoise=None, infill=False,
                        infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
                        infill_noises: Optional[Callable] = None, t_start: Optional[int] = None, t_stop: int = 0,
-                       use_graph: bool = True, sample_offset: int = 0):
+                       use_graph: bool = True, sample_offset: int = 0, global_num_samples: Optional[int] = None):
     """utils/ebm_utils.py:280-405.  Returns (state, collection (41, ...), ld_metrics (4, T, 1)).
 
     epsilon / T / denoise are null parameters as in the reference.  ``noises(t)`` /
     ``infill_noises(t)`` supply the normal draws of :360-362 / :342-345 explicitly (parity mode);
     otherwise the fused reverse-step kernel draws them from Philox keyed by (rng, global sample
-    index, t) and the step is replayed from a captured hipGraph.  ``t_start/t_stop`` bound the
-    walk (default T-1 .. 0)."""
+    index, t) and the step is replayed from a captured hipGraph.  With a ``ThreefryKey`` the draws are the
+    reference's own: the three splits per iteration (:329,342,360) are unrolled on the host into per-iteration
+    key tables and a threefry kernel inside the captured step writes normal(noise_rng) (and normal(infill_rng))
+    for this rank's rows of the (global_num_samples, ...) state.  ``t_start/t_stop`` bound the walk
+    (default T-1 .. 0); the key sequence always starts at the first iteration, like the reference's scan."""
     del epsilon, T, denoise
     eng = model.engine
     dev = eng.device
@@ -228,7 +248,40 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     io.slot_table = eng.slot_table.data_ptr()
     steps = list(range(t_hi, t_stop - 1, -1))
     explicit = noises is not None or infill_noises is not None
-    if explicit:
+    jax_mode = isinstance(rng, ThreefryKey) and not explicit
+    if jax_mode:
+        per = int(np.prod(init.shape[1:]))
+        n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
+        ik, nk = _jr.sampler_key_tables(rng, len(steps))
+        # row i of the tables belongs to the i-th iteration, i.e. t = t_hi - i: index (t_hi - t) on the device
+        nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
+        ik_d = torch.from_numpy(ik.view(np.int32).copy()).to(dev) if infill else None
+        zbuf = torch.zeros_like(x)
+        izbuf = torch.zeros_like(x) if infill else None
+        io.z_in = zbuf.data_ptr()
+        io.infill_z_in = None if izbuf is None else izbuf.data_ptr()
+
+        def jax_step():
+            _jr.fill_normal_from_table(zbuf, nk_d, t_ptr, t_hi + 1, n_total=n_glob, offset=sample_offset * per)
+            if izbuf is not None:
+                _jr.fill_normal_from_table(izbuf, ik_d, t_ptr, t_hi + 1, n_total=n_glob, offset=sample_offset * per)
+            eng.sample_step(io)
+
+        if use_graph and len(steps) > 1:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                jax_step()                               # warm-up (also t = t_hi)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                jax_step()
+            for _ in steps[1:]:
+                graph.replay()
+        else:
+            for _ in steps:
+                jax_step()
+    elif explicit:
         zbuf = torch.zeros_like(x)
         izbuf = torch.zeros_like(x) if infill else None
         io.z_in = zbuf.data_ptr()
@@ -269,7 +322,8 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
 
 
 def sample(scorenet: Model, sigmas, rng: PRNGKey, sample_shape, num_samples=2400, sampling="ald", epsilon=1e-3,
-           steps=100, denoise=True, *, sample_offset: int = 0, use_graph: bool = True):
+           steps=100, denoise=True, *, sample_offset: int = 0, use_graph: bool = True,
+           global_num_samples: Optional[int] = None):
     """train_ncsn.py:499-551 for sampling == 'ddpm' (ald / cas need the NCSN nets that are broken
     upstream; they are a "next" row)."""
     if sampling != "ddpm":
@@ -282,7 +336,13 @@ def sample(scorenet: Model, sigmas, rng: PRNGKey, sample_shape, num_samples=2400
         raise ValueError(f"sample_shape {tuple(sample_shape)} != model shape {eng.cfg.sample_shape}")
     eng.bind(num_samples, training=False)
     init = torch.empty((num_samples, *sample_shape), dtype=torch.float32, device=eng.device)
-    eng.init_state(init, init_rng.seed, sample_offset)                               # :539-540 N(0,1)
+    if isinstance(init_rng, ThreefryKey):                                            # :539-540 N(0,1), jax stream
+        per = int(np.prod(sample_shape))
+        n_glob = (num_samples + sample_offset if global_num_samples is None else int(global_num_samples)) * per
+        _jr.normal(init_rng, init.shape, eng.device, n_total=n_glob, offset=sample_offset * per, out=init)
+    else:
+        eng.init_state(init, init_rng.seed, sample_offset)                           # :539-540 N(0,1)
     generated, collection, ld_metrics = diffusion_dynamics(ld_rng, scorenet, sigmas, init, epsilon, steps, denoise,
-                                                           False, sample_offset=sample_offset, use_graph=use_graph)
+                                                           False, sample_offset=sample_offset, use_graph=use_graph,
+                                                           global_num_samples=global_num_samples)
     return generated, collection, collate_sampling_metrics(ld_metrics.cpu().numpy())

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from .engine import Engine
+from .jax_random import ThreefryKey, diffusion_loss_draws
 from .ncsn import Model, PRNGKey, _ensure_schedule, diffusion_loss
 
 
@@ -83,6 +84,10 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
     world = 1 if comm is None else comm.world_size
     gb = batch.shape[0] * world if global_batch is None else global_batch
+    if isinstance(rng, ThreefryKey) and lab is None and e is None:
+        # the reference's own draws (utils/losses.py:271-294) for this rank's rows of the global batch
+        lab, e = diffusion_loss_draws(rng, tuple(batch.shape), len(sigmas), eng.device, sample_offset=sample_offset,
+                                      global_batch=gb)
     if comm is None:
         eng.loss_backward(batch, lab, e, seed=rng.seed, sample_offset=sample_offset, global_batch=gb, stage=0)
     else:

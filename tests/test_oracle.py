@@ -216,3 +216,73 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text) and "sys.path" not in text, f
+
+
+# ----------------------------------------------------------------------------------------------
+# jax.random restatement: pinned by published known answers
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _kat():
+    import json
+    return json.load(open(os.path.join(GOLDEN, "jax_random_kat.json")))
+
+
+def test_threefry2x32_random123_vectors():
+    for v in _kat()["threefry2x32"]:
+        y0, y1 = O.threefry2x32(v["key"], np.uint32([v["ctr"][0]]), np.uint32([v["ctr"][1]]))
+        assert [int(y0[0]), int(y1[0])] == v["out"]
+
+
+def test_jax_random_known_answers():
+    """Keys and normals printed in JAX's documentation (PRNGKey(0), three generations of split, six normal draws)."""
+    d = _kat()["jax_docs"]
+    key = O.jax_prngkey(0)
+    assert [int(k) for k in key] == d["key0"]
+    n = lambda k: float(O.jax_normal(k, 1)[0])
+    assert n(key) == np.float32(d["normal_key0"])
+    for gen in ("split1", "split2"):
+        key, sub = O.jax_split(key)
+        assert [int(k) for k in key] == d[gen]["key"] and [int(k) for k in sub] == d[gen]["subkey"]
+        assert n(sub) == np.float32(d[gen]["normal_subkey"])
+    key, *subs = O.jax_split(key, 4)
+    assert [n(s) for s in subs] == [np.float32(v) for v in d["split3_of_4"]["normals_subkeys"]]
+
+
+def test_jax_random_bits_layout_and_moments():
+    key = O.jax_prngkey(1234)
+    # the two counter halves: element i < h comes from word 0 of block (i, i+h), element h+i from word 1
+    n = 10
+    b = O.jax_random_bits(key, n)
+    y0, y1 = O.threefry2x32(key, np.arange(5, dtype=np.uint32), np.arange(5, 10, dtype=np.uint32))
+    assert np.array_equal(b, np.concatenate([y0, y1]))
+    # odd size: the pad counter is 0 and its output is dropped
+    b7 = O.jax_random_bits(key, 7)
+    y0, y1 = O.threefry2x32(key, np.uint32([0, 1, 2, 3]), np.uint32([4, 5, 6, 0]))
+    assert np.array_equal(b7, np.concatenate([y0, y1])[:7])
+    z = O.jax_normal(key, 200_000).astype(np.float64)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01 and abs((z ** 3).mean()) < 0.03
+    u = O.jax_uniform(key, 100_000)
+    assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 0.01
+    r = O.jax_randint(key, 100_000, 1, 1001)
+    assert r.min() == 1 and r.max() == 1000 and abs(r.mean() - 500.5) < 3
+    assert np.all(O.jax_randint(key, 16, 5, 5) == 5)             # maxval <= minval -> minval
+
+
+def test_jax_uniform_degenerate_interval_is_minval():
+    """utils/losses.py:283-286 draws uniform(minval=abar[l-1], maxval=abar[l]) with minval > maxval: the trailing
+    max(minval, .) returns minval exactly."""
+    betas = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
+    ap = np.concatenate([np.ones(1, np.float32), O.alphas_cumprod(betas)])
+    labels = O.jax_randint(O.jax_prngkey(3), 256, 1, 1001)
+    got = O.jax_uniform(O.jax_prngkey(4), 256, ap[labels - 1], ap[labels])
+    assert np.array_equal(got, ap[labels - 1])
+    assert np.array_equal(got, O.used_alphas_from_labels(betas, labels).astype(np.float32))
+
+
+def test_jax_erfinv_matches_scipy():
+    from scipy.special import erfinv
+    x = np.linspace(-0.999999, 0.999999, 20001).astype(np.float32)
+    got = O.erfinv_f32(x).astype(np.float64)
+    want = erfinv(x.astype(np.float64))
+    assert np.max(np.abs(got - want) / (1 + np.abs(want))) < 2e-6

@@ -68,7 +68,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
     train_writer = train_utils.JsonlWriter(os.path.join(output_dir, "train")) if rank == 0 else None
     eval_writer = train_utils.JsonlWriter(os.path.join(output_dir, "eval")) if rank == 0 else None
     input_shape = train_batches.sample_shape
-    rng = ncsn.PRNGKey(FLAGS.seed)
+    rng = ncsn.make_key(FLAGS.seed, FLAGS.rng_impl)
     rng, model_rng, sample_rng = ncsn.split(rng, num=3)                          # :318-319
     model_kwargs = dict(num_layers=FLAGS.num_layers, num_heads=FLAGS.num_heads,
                         num_mlp_layers=FLAGS.num_mlp_layers, mlp_dims=FLAGS.mlp_dims)
