@@ -234,6 +234,8 @@ ENGINE_FLAGS: List[FlagDef] = [
     _D("synthetic_examples", "int", 4096, "Synthetic examples per epoch."),
     _D("sample_ema", "bool", False, "sample_ncsn: sample from the EMA weights (reference uses raw weights)."),
     _D("graph", "bool", True, "Capture the sampling step in a hipGraph."),
+    _D("ckpt_format", "enum", "safetensors", "Checkpoint file format written by train_ncsn: safetensors, or the "
+       "reference's flax-0.3.0 msgpack state dict (both are recognised when restoring).", ("safetensors", "flax")),
     _D("rng_impl", "enum", "philox", "Random streams: the engine's fused Philox draws, or jax.random-compatible "
        "threefry2x32 streams (same --seed / --sample_seed => the reference's noise).", ("philox", "threefry")),
 ]

@@ -120,7 +120,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                     if (not FLAGS.early_stopping and FLAGS.save_ckpt) or \
                             (FLAGS.early_stopping and improved and FLAGS.save_ckpt):          # :395-399
                         checkpoint.save_checkpoint(output_dir, (optimizer, ema, early_stop), sampling_step,
-                                                   keep=FLAGS.checkpoints_to_keep)
+                                                   keep=FLAGS.checkpoints_to_keep, fmt=FLAGS.ckpt_format)
                     if FLAGS.snapshot_sampling:                                               # :404-414
                         scorenet = ncsn.Model(model.cfg, dev, seed=None)
                         scorenet.replace(ema.params if FLAGS.ema else optimizer.target.params)
