@@ -7,10 +7,12 @@ image and BASELINE's workloads are synthetic, so this module provides
   * ``ArrayLatents``       the same interface over a NumPy array / .npy / .pkl of latents
   * ``normalize_dataset`` / ``slice_transform`` / ``inverse_data_transform`` (input_pipeline.py:
     36-48,78-110) and ``save`` / ``load`` (utils/data_utils.py:30-41, pickle protocol 4)
-TFRecord ingestion is a "next" row.
+  * ``open_dataset``       the reference's TFRecord shards (tfrecord.py: no TensorFlow) or .npy / .pkl arrays,
+                           with the reference's slice -> batch -> per-split min/max (+ cache pickles) -> normalise order
 """
 from __future__ import annotations
 
+import glob
 import os
 import pickle
 from typing import Iterator, Optional, Sequence
@@ -110,27 +112,66 @@ class SyntheticLatents(ArrayLatents):
         super().__init__(x.numpy(), batch_size, -1.0, 1.0, True, device)
 
 
+def compute_dataset_min_max(batched: np.ndarray, ds_split: str = "train", cache: bool = False,
+                            cache_dir: Optional[str] = None, config: str = ""):
+    """utils/data_utils.py:128-156: min / max over the batched (drop_remainder) split, read from / written to
+    ``{cache_dir}/cache/{split}_{config}_{min,max}.pkl`` (pickled float32 scalars) like the reference."""
+    if cache_dir is not None:
+        min_p = os.path.join(cache_dir, f"cache/{ds_split}_{config}_min.pkl")
+        max_p = os.path.join(cache_dir, f"cache/{ds_split}_{config}_max.pkl")
+        if os.path.exists(min_p) and os.path.exists(max_p):
+            return load(min_p), load(max_p)
+    ds_min, ds_max = np.float32(batched.min()), np.float32(batched.max())
+    if cache and cache_dir is not None:
+        try:
+            save(ds_min, min_p)
+            save(ds_max, max_p)
+        except OSError:                      # read-only dataset directory: the cache is an optimisation only
+            pass
+    return ds_min, ds_max
+
+
+def _config_name(*ckpts: str) -> str:
+    """input_pipeline.py:186-188: concatenated basenames (sans extension) of the pca / slice / dim-weights files."""
+    return "".join((c or "").split("/")[-1].split(".")[0] for c in ckpts)
+
+
 def open_dataset(path: str, batch_size: int, sample_shape: Sequence[int], device=None, rank=0, world_size=1,
-                 normalize=True, slice_idx=None, dim_weights=None):
-    """``--dataset`` as {train,eval}.npy / .pkl arrays of raw latents (N, *shape_raw).  TFRecords
-    (input_pipeline.py:182-207) are not readable without TensorFlow."""
+                 normalize=True, slice_idx=None, dim_weights=None, data_shape: Optional[Sequence[int]] = None,
+                 pca_ckpt: str = "", slice_ckpt: str = "", dim_weights_ckpt: str = "", cache: bool = True):
+    """``--dataset``: the reference's ``{train,eval}-*.tfrecord`` shards (input_pipeline.py:126-139; read without
+    TensorFlow, tfrecord.py) or {train,eval}.npy / .pkl arrays of raw latents (N, *data_shape).
+
+    Order of operations as in get_dataset (:113-235): slice / weight transform -> batch with drop_remainder ->
+    per-split min / max (cached under ``{dataset}/cache``) -> each split normalised with ITS OWN min / max
+    (:189-208).  Records are read in sorted file order (the reference shuffles files and an 8*batch buffer with
+    an unseeded tf.data shuffle)."""
+    from . import tfrecord
+    path = os.path.expanduser(path)
+    raw_shape = tuple(int(v) for v in (data_shape if data_shape is not None else sample_shape))
     out = []
     for split in ("train", "eval"):
         arr = None
-        for ext in (".npy", ".pkl"):
-            f = os.path.join(path, split + ext)
-            if os.path.exists(f):
-                arr = np.load(f) if ext == ".npy" else load(f)
-                break
+        if glob.glob(os.path.join(path, f"{split}-*.tfrecord")):
+            arr = tfrecord.read_latents(os.path.join(path, f"{split}-*.tfrecord"), raw_shape)
+        else:
+            for ext in (".npy", ".pkl"):
+                f = os.path.join(path, split + ext)
+                if os.path.exists(f):
+                    arr = np.load(f) if ext == ".npy" else load(f)
+                    break
         if arr is None:
-            raise FileNotFoundError(
-                f"{path}/{split}.npy|.pkl not found. TFRecord datasets need TensorFlow (not on this image); "
-                "convert them to .npy or pass --synthetic.")
+            raise FileNotFoundError(f"{path}: neither {split}-*.tfrecord nor {split}.npy|.pkl found (or pass --synthetic)")
         arr = slice_transform(np.asarray(arr, np.float32), slice_idx, dim_weights)
-        out.append(arr)
-    dmin, dmax = float(out[0].min()), float(out[0].max())       # train min/max like data_utils.py:128-156
+        out.append(arr[:(len(arr) // batch_size) * batch_size])                 # batch(drop_remainder=True)
+    config = _config_name(pca_ckpt, slice_ckpt, dim_weights_ckpt)
     sets = []
-    for arr in out:
-        a = normalize_dataset(arr, dmin, dmax) if normalize else arr
-        sets.append(ArrayLatents(a.reshape(len(a), *sample_shape), batch_size, dmin, dmax, True, device, rank, world_size))
+    for split, arr in zip(("train", "eval"), out):
+        dmin, dmax = 0.0, 1.0
+        if normalize:
+            dmin, dmax = compute_dataset_min_max(arr, split, cache, path if cache else None, config)
+            arr = normalize_dataset(arr, dmin, dmax)
+        is_train = split == "train"
+        sets.append(ArrayLatents(arr.reshape(len(arr), *sample_shape), batch_size, float(dmin), float(dmax), True, device,
+                                 rank if is_train else 0, world_size if is_train else 1))
     return sets[0], sets[1]

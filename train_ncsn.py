@@ -47,7 +47,9 @@ def build_datasets(FLAGS, sample_shape, device, rank, world):
         valid = data.SyntheticLatents(sample_shape, max(FLAGS.batch_size * 2, 512), FLAGS.batch_size, 4321, device)
     else:
         train, valid = data.open_dataset(FLAGS.dataset, FLAGS.batch_size, sample_shape, device, rank, world,
-                                         FLAGS.normalize, slice_idx, dim_weights)
+                                         FLAGS.normalize, slice_idx, dim_weights, data_shape=[int(v) for v in FLAGS.data_shape],
+                                         pca_ckpt=FLAGS.pca_ckpt, slice_ckpt=FLAGS.slice_ckpt,
+                                         dim_weights_ckpt=FLAGS.dim_weights_ckpt)
     return train, valid, slice_idx, dim_weights
 
 
