@@ -65,28 +65,6 @@ __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
   if (g == 0) a.s_out[b] = sa;
 }
 
-// ------------------------------------------------------------------ loss + gradient wrt pred
-__global__ __launch_bounds__(256) void mse_loss_grad_kernel(const float* __restrict__ pred,
-                                                            const float* __restrict__ eps, int S, int C, int Cp,
-                                                            float inv_global_count,
-                                                            float* __restrict__ loss_per_sample,
-                                                            bf16_t* __restrict__ dpred) {
-  __shared__ float red[4];
-  const int b = blockIdx.x, SC = S * C;
-  float acc = 0.f;
-  for (int e = threadIdx.x; e < SC; e += 256) {
-    const float d = pred[(size_t)b * SC + e] - eps[(size_t)b * SC + e];
-    acc += d * d;
-    const int srow = e / C, c = e - srow * C;
-    dpred[((size_t)b * S + srow) * Cp + c] = f2bf(2.0f * d * inv_global_count);
-  }
-  acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) loss_per_sample[b] = (red[0] + red[1] + red[2] + red[3]) / (float)SC;
-}
-
-// ------------------------------------------------------------------ fused reverse step
 template <int VEC> struct VecT;
 template <> struct VecT<4> { typedef float4 type; };
 template <> struct VecT<1> { typedef float type; };
@@ -106,10 +84,58 @@ __device__ __forceinline__ void stv(float* p, const float (&v)[VEC]) {
   else *p = v[0];
 }
 
+// ------------------------------------------------------------------ loss + gradient wrt pred
+// one workgroup of 1024 threads per sample; VEC = 4: 16-byte loads / 8-byte bf16 stores (C and Cp multiples of 4)
 template <int VEC>
-__global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
+__global__ __launch_bounds__(1024) void mse_loss_grad_kernel(const float* __restrict__ pred,
+                                                             const float* __restrict__ eps, int S, int C, int Cp,
+                                                             float inv_global_count,
+                                                             float* __restrict__ loss_per_sample,
+                                                             bf16_t* __restrict__ dpred) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, SC = S * C;
+  float acc = 0.f;
+  for (int e = threadIdx.x * VEC; e < SC; e += 1024 * VEC) {
+    float p[VEC], q[VEC];
+    ldv<VEC>(pred + (size_t)b * SC + e, p);
+    ldv<VEC>(eps + (size_t)b * SC + e, q);
+    const int srow = e / C, c = e - srow * C;
+    bf16_t* dst = dpred + ((size_t)b * S + srow) * Cp + c;
+    if constexpr (VEC == 4) {
+      bf16x4_t o;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float d = p[v] - q[v];
+        acc += d * d;
+        o[v] = f2bf(2.0f * d * inv_global_count);
+      }
+      *reinterpret_cast<bf16x4_t*>(dst) = o;
+    } else {
+      const float d = p[0] - q[0];
+      acc += d * d;
+      dst[0] = f2bf(2.0f * d * inv_global_count);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    loss_per_sample[b] = t / (float)SC;
+  }
+}
+
+// ------------------------------------------------------------------ fused reverse step
+// One workgroup per sample: 128 column threads x RG row groups (RG = 4 for sequence states: four rows of every column
+// in flight instead of one; the per-column sums over the sequence axis are combined through LDS in a fixed order).
+template <int VEC, int RG>
+__global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs a) {
   __shared__ float red[2][3];
+  __shared__ float part[RG > 1 ? RG : 1][3][128 * VEC];
   const int b = blockIdx.x;
+  const int ct = threadIdx.x & 127, rg = threadIdx.x >> 7;
   const int t = *a.t_ptr;
   const float* cf = a.coef + (size_t)t * 8;
   const float sqrt_recip = cf[0], sqrt_m1 = cf[1], mu1 = cf[2], mu2 = cf[3], sigma = cf[4];
@@ -119,11 +145,13 @@ __global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
   const uint32_t bglob = (uint32_t)b + a.sample_offset;
   const size_t sample_base = (size_t)b * a.S * a.C;
   float m_eps = 0.f, m_step = 0.f, m_z = 0.f;
-  for (int col0 = threadIdx.x * VEC; col0 < a.C; col0 += 128 * VEC) {
+  for (int cb = 0; cb < a.C; cb += 128 * VEC) {            // uniform trip count: the LDS combine below has barriers
+    const int col0 = cb + ct * VEC;
+    const bool live = col0 < a.C;
     float acc_e[VEC], acc_s[VEC], acc_z[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc_e[v] = acc_s[v] = acc_z[v] = 0.f;
-    for (int s = 0; s < a.S; ++s) {
+    for (int s = rg; live && s < a.S; s += RG) {
       const int e = s * a.C + col0;
       const size_t idx = sample_base + e;
       float x[VEC], eh[VEC], z[VEC], nx[VEC];
@@ -191,8 +219,28 @@ __global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
         }
       }
     }
+    if constexpr (RG > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        part[rg][0][ct * VEC + v] = acc_e[v]; part[rg][1][ct * VEC + v] = acc_s[v]; part[rg][2][ct * VEC + v] = acc_z[v];
+      }
+      __syncthreads();
+      if (rg == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float se = 0.f, ss = 0.f, sz = 0.f;
+#pragma unroll
+          for (int g2 = 0; g2 < RG; ++g2) {
+            se += part[g2][0][ct * VEC + v]; ss += part[g2][1][ct * VEC + v]; sz += part[g2][2][ct * VEC + v];
+          }
+          acc_e[v] = se; acc_s[v] = ss; acc_z[v] = sz;
+        }
+      }
+    }
     // :381-383 sqrt(sum(v^2, axis=1) + 1e-10): axis 1 is the SEQUENCE axis for (B,S,C) states and the
     // channel axis for the 2-D (B,C) states of DenseDDPM (S == 1 here).
+    if (rg == 0 && live)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       if (a.S > 1) {
@@ -207,7 +255,7 @@ __global__ __launch_bounds__(128) void reverse_step_kernel(ReverseStepArgs a) {
   if (a.metrics_partial) {
     m_eps = wave_sum(m_eps); m_step = wave_sum(m_step); m_z = wave_sum(m_z);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[w][0] = m_eps; red[w][1] = m_step; red[w][2] = m_z; }
+    if ((threadIdx.x & 63) == 0 && w < 2) { red[w][0] = m_eps; red[w][1] = m_step; red[w][2] = m_z; }
     __syncthreads();
     if (threadIdx.x < 3) {
       float v = red[0][threadIdx.x] + red[1][threadIdx.x];
@@ -267,8 +315,12 @@ int launch_mse_loss_grad(const float* pred, const float* eps, int B, int S, int 
                          float* loss_per_sample, bf16_t* dpred_bf16, hipStream_t st) {
   SMD_ARG_CHECK(pred && eps && loss_per_sample && dpred_bf16 && B > 0 && S > 0 && C > 0 && Cp >= C,
                 "mse_loss_grad: bad arguments");
-  hipLaunchKernelGGL(mse_loss_grad_kernel, dim3(B), dim3(256), 0, st, pred, eps, S, C, Cp, inv_global_count,
-                     loss_per_sample, dpred_bf16);
+  if (C % 4 == 0 && Cp % 4 == 0)
+    hipLaunchKernelGGL(mse_loss_grad_kernel<4>, dim3(B), dim3(1024), 0, st, pred, eps, S, C, Cp, inv_global_count,
+                       loss_per_sample, dpred_bf16);
+  else
+    hipLaunchKernelGGL(mse_loss_grad_kernel<1>, dim3(B), dim3(1024), 0, st, pred, eps, S, C, Cp, inv_global_count,
+                       loss_per_sample, dpred_bf16);
   SMD_LAUNCH_CHECK();
   return 0;
 }
@@ -278,10 +330,14 @@ int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && (!a.x_bf16 || a.Cp >= a.C), "reverse_step: bad shape");
   SMD_ARG_CHECK((a.infill_masks != nullptr) == (a.infill_samples != nullptr), "reverse_step: infill needs samples and masks");
   SMD_ARG_CHECK(!a.collection || a.slot_table, "reverse_step: collection needs slot_table");
-  if (a.C % 4 == 0 && (!a.x_bf16 || a.Cp % 4 == 0))
-    hipLaunchKernelGGL(reverse_step_kernel<4>, dim3(a.B), dim3(128), 0, st, a);
-  else
-    hipLaunchKernelGGL(reverse_step_kernel<1>, dim3(a.B), dim3(128), 0, st, a);
+  const bool vec = a.C % 4 == 0 && (!a.x_bf16 || a.Cp % 4 == 0);
+  if (a.S >= 4) {
+    if (vec) hipLaunchKernelGGL((reverse_step_kernel<4, 4>), dim3(a.B), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((reverse_step_kernel<1, 4>), dim3(a.B), dim3(512), 0, st, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((reverse_step_kernel<4, 1>), dim3(a.B), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((reverse_step_kernel<1, 1>), dim3(a.B), dim3(128), 0, st, a);
+  }
   SMD_LAUNCH_CHECK();
   return 0;
 }

@@ -661,8 +661,24 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
   const int S = d_.seq_len, C = d_.data_channels;
   if (stage == 0 || stage == 1 || stage == 3) {     // 3 = loss only (eval_step, train_ncsn.py:206-221)
     SMD_ARG_CHECK(x0, "loss_backward: null batch");
+    hipEvent_t grads_zeroed = nullptr;
     if (stage != 3) {
-      hipError_t e = hipMemsetAsync(grads_, 0, sizeof(float) * (size_t)n_params_, st);
+      // zero the gradient buffer; with the side stream on, the 106 MB memset runs there underneath the forward pass
+      // (ordered after everything enqueued so far, i.e. after the previous optimiser step) and the main stream
+      // picks its completion up just before the first gradient is written
+      hipStream_t ms = st;
+      if (side_wgrad && side_) {
+        hipEvent_t ev0 = take_event();
+        grads_zeroed = take_event();
+        SMD_ARG_CHECK(ev0 && grads_zeroed, "loss_backward: cannot create an event");
+        hipError_t e0 = hipEventRecord(ev0, st);
+        if (e0 == hipSuccess) e0 = hipStreamWaitEvent(side_, ev0, 0);
+        if (e0 != hipSuccess) { smd_set_error("loss_backward: %s", hipGetErrorString(e0)); return (int)e0; }
+        ms = side_;
+        side_pending_ = true;
+      }
+      hipError_t e = hipMemsetAsync(grads_, 0, sizeof(float) * (size_t)n_params_, ms);
+      if (e == hipSuccess && grads_zeroed) e = hipEventRecord(grads_zeroed, side_);
       if (e != hipSuccess) { smd_set_error("loss_backward: memset: %s", hipGetErrorString(e)); return (int)e; }
     }
     QSampleArgs q;
@@ -674,6 +690,10 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     RC(launch_q_sample(q, st));
     RC(run_network(nullptr, st));
     RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st));
+    if (grads_zeroed) {
+      hipError_t e = hipStreamWaitEvent(st, grads_zeroed, 0);
+      if (e != hipSuccess) { smd_set_error("loss_backward: %s", hipGetErrorString(e)); return (int)e; }
+    }
     if (stage != 3) RC(backward_head(st));
     if (stage == 1) {                              // output-stage gradients must be final before the DP all-reduce
       RC(flush_ln_reduce(st));

@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void recast_weight_kernel(const float* __restr
   }
 }
 
-// every Dense kernel of the model in ONE launch: block -> (weight, 64x64 tile) through a small table
+// every Dense kernel of the model in ONE launch: block -> (weight, 64x64 tile) through a small table.
+// Interior tiles of 16-byte-aligned weights move as float4 loads and 8-byte bf16 stores in both orientations (thread
+// = 4 consecutive n for W, 4 consecutive k for Wt, through a padded LDS tile); edge or unaligned tiles go scalar.
 __global__ __launch_bounds__(256) void recast_all_kernel(const float* __restrict__ params, bf16_t* __restrict__ wpack,
                                                          RecastTable t) {
   __shared__ float tile[64][65];
@@ -147,6 +149,30 @@ __global__ __launch_bounds__(256) void recast_all_kernel(const float* __restrict
   const float* w = params + e.w_off;
   bf16_t* W = wpack + e.W_off;
   bf16_t* Wt = wpack + e.Wt_off;
+  const bool full = k0 + 64 <= (int)e.K && n0 + 64 <= (int)e.N;
+  const bool aligned = ((e.w_off | e.N | e.W_off | e.ldw | e.Wt_off | e.ldwt) & 3u) == 0;
+  if (full && aligned) {
+    const int c4 = (threadIdx.x & 15) * 4, r = threadIdx.x >> 4;          // 16 threads per row, 16 rows per pass
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int k = r + 16 * p;
+      const float4 v = *reinterpret_cast<const float4*>(w + (size_t)(k0 + k) * e.N + n0 + c4);
+      bf16x4_t o;
+      o[0] = f2bf(v.x); o[1] = f2bf(v.y); o[2] = f2bf(v.z); o[3] = f2bf(v.w);
+      *reinterpret_cast<bf16x4_t*>(W + (size_t)(k0 + k) * e.ldw + n0 + c4) = o;
+      tile[k][c4 + 0] = v.x; tile[k][c4 + 1] = v.y; tile[k][c4 + 2] = v.z; tile[k][c4 + 3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int n = r + 16 * p;                                            // row of Wt; this thread: k = c4 .. c4+3
+      bf16x4_t o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = f2bf(tile[c4 + j][n]);
+      *reinterpret_cast<bf16x4_t*>(Wt + (size_t)(n0 + n) * e.ldwt + k0 + c4) = o;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int k = k0 + i, n = n0 + tx;
