@@ -131,6 +131,86 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(LnArgs a) {
   store_row_bf16<D>(a.out, row, lane, y);
 }
 
+// a row held raw in registers (converted at use)
+template <int D, bool XBF> struct WideRow {
+  typedef RowLayout<D> L;
+  float4 xf[XBF ? 1 : L::NV];
+  bf16x4_t xb[XBF ? L::NV : 1];
+  bf16x4_t dy[L::NV];
+  __device__ __forceinline__ float x(int k, int e) const {
+    if constexpr (XBF) return bf2f(xb[k][e]);
+    else return e == 0 ? xf[k].x : e == 1 ? xf[k].y : e == 2 ? xf[k].z : xf[k].w;
+  }
+};
+
+// Wide rows (D = 1024 / 2048) in row groups: the one-wave-per-row kernel above re-reads gamma / beta (/ FiLM scale /
+// shift) from the L2 for every row -- 4x the bytes of the row itself.  Here a workgroup of 8 waves owns one row group
+// (a sample's rows with per-sample FiLM, else 32 rows), keeps the parameters in LDS and walks the group's rows
+// (SGPR row bases, all of a row's loads issued up front).  FS: FiLM + swish (ResBlock norms) or neither.
+template <int D, bool XBF, bool FS>
+__global__ __launch_bounds__(512) void layernorm_fwd_wide_kernel(LnArgs a, int group_rows) {
+  typedef RowLayout<D> L;
+  constexpr int NV = L::NV, NW = 8;
+  __shared__ __attribute__((aligned(16))) float prm[FS ? 4 : 2][D];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r_begin = blockIdx.x * group_rows;
+  int r_end = r_begin + group_rows;
+  r_end = r_end < a.rows ? r_end : a.rows;
+  {
+    const int frow = FS ? (a.t_ptr ? *a.t_ptr : r_begin / a.rows_per_sample) : 0;
+    const float* src[4] = {a.gamma, a.beta, FS ? a.film_scale + (size_t)frow * a.ld_film : nullptr,
+                           FS ? a.film_shift + (size_t)frow * a.ld_film : nullptr};
+#pragma unroll
+    for (int q = 0; q < (FS ? 4 : 2); ++q)
+      for (int c = threadIdx.x * 4; c < D; c += 2048)
+        *reinterpret_cast<float4*>(&prm[q][c]) = *reinterpret_cast<const float4*>(src[q] + c);
+  }
+  __syncthreads();
+  const uint32_t l4 = lane * 4;
+  for (int row = r_begin + w; row < r_end; row += NW) {
+    WideRow<D, XBF> b;                       // dy unused here
+    const float* xr = a.x + (size_t)row * D;
+    const bf16_t* xbr = a.x_bf16 + (size_t)row * D;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if constexpr (XBF) b.xb[k] = *reinterpret_cast<const bf16x4_t*>(xbr + (l4 + k * 256));
+      else b.xf[k] = *reinterpret_cast<const float4*>(xr + (l4 + k * 256));
+    }
+    float s = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float v = b.x(k, e); s += v; sq += v * v; }
+    s = wave_sum(s);
+    sq = wave_sum(sq);
+    const float mean = s * (1.0f / D);
+    const float rstd = rsqrtf(sq * (1.0f / D) - mean * mean + LN_EPS);
+    bf16_t* orow = a.out + (size_t)row * D;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int c = k * 256 + lane * 4;
+      const float4 g4 = *reinterpret_cast<const float4*>(&prm[0][c]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&prm[1][c]);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = (b.x(k, e) - mean) * rstd * gg[e] + bb[e];
+      if constexpr (FS) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&prm[2][c]);
+        const float4 h4 = *reinterpret_cast<const float4*>(&prm[3][c]);
+        const float ss[4] = {s4.x, s4.y, s4.z, s4.w}, hh[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = swishf_(ss[e] * y[e] + hh[e]);
+      }
+      bf16x4_t t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = f2bf(y[e]);
+      *reinterpret_cast<bf16x4_t*>(orow + (l4 + k * 256)) = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ backward
 // One workgroup = one row group (a sample's rows_per_sample rows when FiLM is on, else 32 rows);
 // wave w walks rows w, w+4, ... ; per-column sums live in registers and are combined through LDS.
@@ -382,16 +462,6 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_wide_kernel(LnBwdDev a) 
 //     use); the per-element dh = e*scale*gamma is parked in a per-wave LDS row between the column pass and the dx
 //     pass and xhat is recomputed from raw x, so a wave needs ~150 VGPRs and the row bases live in SGPRs;
 //   * the residual gradient may be bf16 (RM = 2): the engine keeps the ResBlock residual-gradient chain in bf16.
-template <int D, bool XBF> struct WideRow {
-  typedef RowLayout<D> L;
-  float4 xf[XBF ? 1 : L::NV];
-  bf16x4_t xb[XBF ? L::NV : 1];
-  bf16x4_t dy[L::NV];
-  __device__ __forceinline__ float x(int k, int e) const {
-    if constexpr (XBF) return bf2f(xb[k][e]);
-    else return e == 0 ? xf[k].x : e == 1 ? xf[k].y : e == 2 ? xf[k].z : xf[k].w;
-  }
-};
 
 template <int D, bool XBF, int RM, bool FS, int OM>   // FS: FiLM + swish (the ResBlock norms) or neither (plain
 __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) {   // LayerNorm); OM: 1 fp32 dx, 2 bf16, 3 both
@@ -782,6 +852,18 @@ static int check_ln(const LnArgs& a, bool need_out) {
   }
 
 template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
+  if constexpr (D == 1024 || D == 2048) {
+    const bool fs = a.film_scale && a.swish, plain = !a.film_scale && !a.swish;
+    const int gr = (a.film_scale && !a.t_ptr) ? a.rows_per_sample : 32;
+    if (smd_tuning_get("ln_fwd_wide") && (fs || plain) && gr >= 8) {
+      const int ng = (a.rows + gr - 1) / gr;
+#define SMD_FW(XB, FS_) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_>), dim3(ng), dim3(512), 0, st, a, gr)
+      if (a.x_bf16) { if (fs) SMD_FW(true, true); else SMD_FW(true, false); }
+      else          { if (fs) SMD_FW(false, true); else SMD_FW(false, false); }
+#undef SMD_FW
+      return;
+    }
+  }
   hipLaunchKernelGGL(layernorm_fwd_kernel<D>, dim3((a.rows + 3) / 4), dim3(256), 0, st, a);
 }
 template <int D> static void run_bwd(const LnBwdDev& d, int ngroups, hipStream_t st) {
