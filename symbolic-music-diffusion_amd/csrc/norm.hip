@@ -459,8 +459,7 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_wide_kernel(LnBwdDev a) 
 // row loads nor loads while it computes (2 - 3.4 TB/s in the training step).  Here
 //   * 8 waves share a row group (2 per SIMD), each walks rows w, w+8, ...;
 //   * all of a row's loads (x, dy, residual gradient) are issued up front and stay raw in registers (converted at
-//     use); the per-element dh = e*scale*gamma is parked in a per-wave LDS row between the column pass and the dx
-//     pass and xhat is recomputed from raw x, so a wave needs ~150 VGPRs and the row bases live in SGPRs;
+//     use), xhat is recomputed from raw x in the dx pass, the row bases live in SGPRs;
 //   * the residual gradient may be bf16 (RM = 2): the engine keeps the ResBlock residual-gradient chain in bf16.
 
 template <int D, bool XBF, int RM, bool FS, int OM>   // FS: FiLM + swish (the ResBlock norms) or neither (plain
@@ -469,7 +468,8 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
   constexpr int PL = L::PER_LANE, NV = L::NV, NW = 8;
   constexpr bool film = FS, swish = FS;
   __shared__ __attribute__((aligned(16))) float prm[4][D];      // gamma, beta, scale, shift; later the combine buffer
-  __shared__ __attribute__((aligned(16))) float park[NW][D];    // per-wave dh row
+  // dh stays in registers: with 32 KiB of LDS a workgroup of this kernel still fits beside a 128-KiB wgrad workgroup
+  // of the side stream (an LDS-parked dh row per wave, 96 KiB in all, made every launch queue behind the wgrads)
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform -> row bases live in SGPRs
   const int grp = blockIdx.x;
@@ -491,7 +491,6 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
   float P[PL], Q[PL];
 #pragma unroll
   for (int i = 0; i < PL; ++i) P[i] = Q[i] = 0.f;
-  float* mypark = &park[w][lane * 4];
   const uint32_t l4 = lane * 4;                     // element offset of this lane inside a 256-column chunk
 
   auto issue = [&](int row, WideRow<D, XBF>& b) {
@@ -506,14 +505,13 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  auto compute = [&](int row, const WideRow<D, XBF>& b) {
-    bf16x4_t rb[RM == 2 ? NV : 1];
-    if constexpr (RM == 2) {           // bf16 residual rows: in flight behind the whole row's arithmetic
-      const bf16_t* rr_b = a.dres_bf16 + (size_t)row * D;
+  auto compute = [&](int row, WideRow<D, XBF>& b) {
+    auto fence_x = [&]() {             // bf16 rows: re-convert per pass instead of keeping 32 converted registers alive
+      if constexpr (XBF) {
 #pragma unroll
-      for (int k = 0; k < NV; ++k) rb[k] = *reinterpret_cast<const bf16x4_t*>(rr_b + (l4 + k * 256));
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int k = 0; k < NV; ++k) asm volatile("" : "+v"(b.xb[k]));
+      }
+    };
     // pass 1: row statistics straight from the raw registers
     float s = 0.f, sq = 0.f;
 #pragma unroll
@@ -524,8 +522,10 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
     sq = wave_sum(sq);
     const float mean = s * (1.0f / D);
     const float rstd = rsqrtf(sq * (1.0f / D) - mean * mean + LN_EPS);
-    // pass 2: column sums P, Q and the row sums; dh parked in LDS
+    fence_x();
+    // pass 2: column sums P, Q and the row sums
     float s1 = 0.f, s2 = 0.f;
+    float dhr[PL];
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = k * 256 + lane * 4;
@@ -539,7 +539,6 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
         ss[0] = s4.x; ss[1] = s4.y; ss[2] = s4.z; ss[3] = s4.w;
         hh[0] = h4.x; hh[1] = h4.y; hh[2] = h4.z; hh[3] = h4.w;
       }
-      float dh[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int i = k * 4 + e;
@@ -548,21 +547,28 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
         if constexpr (swish) d *= swish_gradf_(ss[e] * (xh * gg[e] + bb[e]) + hh[e]);
         Q[i] += d;
         P[i] += d * xh;
-        dh[e] = d * ss[e] * gg[e];
-        s1 += dh[e];
-        s2 += dh[e] * xh;
+        const float dhe = d * ss[e] * gg[e];
+        dhr[i] = dhe;
+        s1 += dhe;
+        s2 += dhe * xh;
       }
-      *reinterpret_cast<float4*>(mypark + k * 256) = make_float4(dh[0], dh[1], dh[2], dh[3]);
       __builtin_amdgcn_sched_barrier(0);    // keep the LDS parameter reads of later chunks from being hoisted (VGPRs)
     }
     s1 = wave_sum(s1) * (1.0f / D);
     s2 = wave_sum(s2) * (1.0f / D);
+    fence_x();
     // pass 3: dx = rstd * (dh - mean(dh) - xhat * mean(dh * xhat)) (+ residual gradient)
     float4 rf[RM == 1 ? NV : 1];
-    if constexpr (RM == 1) {           // fp32 residual rows: all loads first (dres may alias dx: the stores below pin them)
+    bf16x4_t rb[RM == 2 ? NV : 1];
+    if constexpr (RM == 1) {           // residual rows: all loads first (dres may alias dx: the stores below pin them)
       const float* rr_f = a.dres + (size_t)row * D;
 #pragma unroll
       for (int k = 0; k < NV; ++k) rf[k] = *reinterpret_cast<const float4*>(rr_f + (l4 + k * 256));
+    }
+    if constexpr (RM == 2) {
+      const bf16_t* rr_b = a.dres_bf16 + (size_t)row * D;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) rb[k] = *reinterpret_cast<const bf16x4_t*>(rr_b + (l4 + k * 256));
     }
     float* of = (OM & 1) ? a.dx_f32 + (size_t)row * D : nullptr;
     bf16_t* ob = (OM & 2) ? a.dx_bf16 + (size_t)row * D : nullptr;
@@ -575,8 +581,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
 #pragma unroll
         for (int e = 0; e < 4; ++e) rr[e] = bf2f(rb[k][e]);
       }
-      const float4 d4 = *reinterpret_cast<const float4*>(mypark + k * 256);
-      const float dh[4] = {d4.x, d4.y, d4.z, d4.w};
+      const float dh[4] = {dhr[k * 4 + 0], dhr[k * 4 + 1], dhr[k * 4 + 2], dhr[k * 4 + 3]};
       float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = (rstd * dh[e] - m2 * b.x(k, e) - c0) + rr[e];
