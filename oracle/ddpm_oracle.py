@@ -13,6 +13,11 @@ the reference's own call sites line by line and restates the published flax/jax
 layer semantics (the ORACLE_ASSUMPTIONS table below); it is pinned only by the
 closed-form known-answer tests in tests/test_oracle.py.
 
+Exception -- PINNED: the jax.random restatement at the end of this file (threefry2x32,
+PRNGKey / split / random_bits layout, uniform, normal) reproduces published known
+answers: the Random123 threefry2x32 vectors and the keys / normal draws printed in
+JAX's documentation (tests/golden/jax_random_kat.json).  randint stays unpinned.
+
 Every function cites the reference file:line it follows (paths relative to the
 reference repo root).  Arithmetic is torch-CPU; dtype is a parameter (float64 for
 parity checks, float32 for the timed CPU baseline).
