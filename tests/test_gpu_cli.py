@@ -91,3 +91,33 @@ def test_train_then_sample_and_infill(workdir):
     gi = D.load(str(itp / "ncsn" / "generated.pkl"))
     assert gi.shape == (9, 4, 32, 512) and np.isfinite(gi).all()                 # 9 interpolation points (:425-435)
     assert not os.path.exists(itp / "ncsn" / "collection.pkl")                   # not written when interpolating (:455-456)
+
+
+def test_config1_dense_ddpm_end_to_end(tmp_path):
+    """configs/ddpm-mel-1seq-512.cfg (DenseDDPM on (8, 512) vectors, --ema): a few
+    epochs of training on a small fixed set, loss finite and decreasing, then the full 1000-step sampler."""
+    import json
+    import smd_amd.data as D
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((4, 512)).astype(np.float32)
+    for split, n in (("train", 64), ("eval", 16)):
+        x = base[rng.integers(0, 4, n)] + 0.05 * rng.standard_normal((n, 512)).astype(np.float32)
+        D.save(x, str(tmp_path / "ds" / f"{split}.pkl"))
+    flags = ["--flagfile=configs/ddpm-mel-1seq-512.cfg", f"--dataset={tmp_path / 'ds'}", f"--model_dir={tmp_path / 'model'}",
+             "--batch_size=8", "--num_layers=2", "--mlp_dims=256"]
+    run("train_ncsn.py", *flags, "--epochs=12", "--logging_freq=1", "--snapshot_freq=1000", "--learning_rate=2e-3")
+    rows = [json.loads(l) for l in open(tmp_path / "model" / "train" / "scalars.jsonl")]
+    loss = [r["value"] for r in rows if r["tag"] == "loss"]
+    assert len(loss) == 96 and np.isfinite(loss).all()                  # 12 epochs x 8 batches
+    # eps-prediction MSE starts near 2 (random output + unit-variance target) and falls towards ~1 (most noise levels of
+    # the linear schedule leave x_t ~ x_0, where eps is not inferable) within a few dozen steps
+    assert np.mean(loss[-16:]) < 0.75 * np.mean(loss[:4]), (np.mean(loss[:4]), np.mean(loss[-16:]))
+    lr = [r["value"] for r in rows if r["tag"] == "lr"]
+    assert abs(lr[0] - 2e-3) < 1e-9
+    out = tmp_path / "samples"
+    run("sample_ncsn.py", *flags, "--sample_size=8", f"--sampling_dir={out}")
+    gen = D.load(str(out / "ncsn" / "generated.pkl"))
+    coll = D.load(str(out / "ncsn" / "collection.pkl"))
+    assert gen.shape == (8, 512) and coll.shape == (41, 8, 512) and np.isfinite(gen).all()
+    lo, hi = D.load(str(tmp_path / "ds" / "cache" / "train__min.pkl")), D.load(str(tmp_path / "ds" / "cache" / "train__max.pkl"))
+    assert gen.min() >= lo - 1e-4 and gen.max() <= hi + 1e-4              # x0 is clipped to [-1, 1] at t = 0
