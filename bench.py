@@ -169,16 +169,13 @@ def main():
     io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B
     io.metrics_partial, io.collection, io.slot_table = metrics_partial.data_ptr(), collection.data_ptr(), eng.slot_table.data_ptr()
     graph = None
-    if a.rng_impl == "threefry":          # the reference's per-iteration noise keys, normals drawn by the threefry kernel
+    if a.rng_impl == "threefry":          # the reference's per-iteration noise keys; normals drawn inside the fused step
         import smd_amd.jax_random as J
         _ik, nk = J.sampler_key_tables(N.make_key(7, "threefry"), 1000)
         nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
-        zbuf = torch.zeros_like(x)
-        io.z_in = zbuf.data_ptr()
+        io.tf_noise_keys, io.tf_n_total, io.tf_t0 = nk_d.data_ptr(), world * B * 32 * 512, 999
 
     def sample_step():
-        if a.rng_impl == "threefry":
-            J.fill_normal_from_table(zbuf, nk_d, t_ptr, 1000, n_total=world * B * 32 * 512, offset=rank * B * 32 * 512)
         eng.sample_step(io)
 
     def one_sample():

@@ -110,6 +110,13 @@ typedef struct smd_sample_io {
   float* metrics_partial;          /* [T][B][3] or NULL */
   float* collection;               /* [41][B][S][C] or NULL */
   const int32_t* slot_table;       /* [T] collection slot for timestep t, -1 = none */
+  /* jax.random streams drawn inside the fused step (utils/ebm_utils.py:342-345,360-362): per-iteration key tables
+   * [iterations][2] (uint32 pairs, row tf_t0 - t), NULL = Philox / explicit z.  The state is rows
+   * [sample_offset, sample_offset + B) of a global (N, S, C) array of tf_n_total elements. */
+  const uint32_t* tf_noise_keys;
+  const uint32_t* tf_infill_keys;
+  int64_t tf_n_total;
+  int32_t tf_t0;
 } smd_sample_io;
 int smd_engine_prepare_sampler(smd_engine* e, void* stream);
 int smd_engine_init_state(smd_engine* e, float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset,

@@ -8,6 +8,7 @@
 // All per-step scalars (timestep t, optimiser step) are read from device memory so the whole
 // step is hipGraph-replayable with frozen kernel arguments.
 #include "smd_kernels.h"
+#include "rng_threefry.h"
 #include "rng.h"
 
 namespace {
@@ -144,6 +145,10 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
   const int slot = a.collection ? a.slot_table[t] : -1;
   const uint32_t bglob = (uint32_t)b + a.sample_offset;
   const size_t sample_base = (size_t)b * a.S * a.C;
+  const uint64_t tf_base = (uint64_t)bglob * a.S * a.C;       // this sample's first element in the global jax array
+  TfKey tf_nk{0, 0}, tf_ik{0, 0};
+  if (a.tf_noise_keys) { tf_nk.k0 = a.tf_noise_keys[2 * (a.tf_t0 - t)]; tf_nk.k1 = a.tf_noise_keys[2 * (a.tf_t0 - t) + 1]; }
+  if (a.tf_infill_keys) { tf_ik.k0 = a.tf_infill_keys[2 * (a.tf_t0 - t)]; tf_ik.k1 = a.tf_infill_keys[2 * (a.tf_t0 - t) + 1]; }
   float m_eps = 0.f, m_step = 0.f, m_z = 0.f;
   for (int cb = 0; cb < a.C; cb += 128 * VEC) {            // uniform trip count: the LDS combine below has barriers
     const int col0 = cb + ct * VEC;
@@ -160,6 +165,9 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
       if (noisy) {                                               // utils/ebm_utils.py:360-364
         if (a.z_in) {
           ldv<VEC>(a.z_in + idx, z);
+        } else if (a.tf_noise_keys) {                            // jax.random.normal(noise_rng, state.shape) (:361-362)
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) z[v] = jax_normal_from_bits(jax_bits_at(tf_nk, tf_base + e + v, (uint64_t)a.tf_n_total));
         } else {
           const float4 n4 = philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_Z, (uint32_t)t,
                                            a.key.seed_lo, a.key.seed_hi);
@@ -185,6 +193,9 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
         if (noisy) {
           if (a.infill_z_in) {
             ldv<VEC>(a.infill_z_in + idx, iz);
+          } else if (a.tf_infill_keys) {                         // jax.random.normal(infill_noise_rng, ...) (:343-345)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) iz[v] = jax_normal_from_bits(jax_bits_at(tf_ik, tf_base + e + v, (uint64_t)a.tf_n_total));
           } else {
             const float4 n4 = philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_INFILL, (uint32_t)t,
                                              a.key.seed_lo, a.key.seed_hi);
@@ -330,6 +341,9 @@ int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && (!a.x_bf16 || a.Cp >= a.C), "reverse_step: bad shape");
   SMD_ARG_CHECK((a.infill_masks != nullptr) == (a.infill_samples != nullptr), "reverse_step: infill needs samples and masks");
   SMD_ARG_CHECK(!a.collection || a.slot_table, "reverse_step: collection needs slot_table");
+  SMD_ARG_CHECK(!(a.tf_noise_keys || a.tf_infill_keys) || (a.tf_n_total >= (int64_t)(a.sample_offset + a.B) * a.S * a.C &&
+                                                            a.tf_n_total <= (1ll << 32)),
+                "reverse_step: tf_n_total=%lld must cover this rank's window and be <= 2^32", (long long)a.tf_n_total);
   const bool vec = a.C % 4 == 0 && (!a.x_bf16 || a.Cp % 4 == 0);
   if (a.S >= 4) {
     if (vec) hipLaunchKernelGGL((reverse_step_kernel<4, 4>), dim3(a.B), dim3(512), 0, st, a);

@@ -56,6 +56,10 @@ struct SampleStepIO {
   float* metrics_partial = nullptr;   // [T][B][3]
   float* collection = nullptr;        // [41][B][S][C]
   const int* slot_table = nullptr;    // [T]
+  const uint32_t* tf_noise_keys = nullptr;   // jax.random key tables (see ReverseStepArgs)
+  const uint32_t* tf_infill_keys = nullptr;
+  int64_t tf_n_total = 0;
+  int tf_t0 = 0;
 };
 
 class SmdEngine {

@@ -764,6 +764,7 @@ int SmdEngine::sample_step(const SampleStepIO& io, hipStream_t st) {
   a.coef = coef_; a.t_ptr = io.t_ptr; a.z_in = io.z_in; a.key = RngKey{io.seed_lo, io.seed_hi};
   a.sample_offset = io.sample_offset;
   a.infill_samples = io.infill_samples; a.infill_masks = io.infill_masks; a.infill_z_in = io.infill_z_in;
+  a.tf_noise_keys = io.tf_noise_keys; a.tf_infill_keys = io.tf_infill_keys; a.tf_n_total = io.tf_n_total; a.tf_t0 = io.tf_t0;
   a.x_bf16 = W.x_bf16; a.metrics_partial = io.metrics_partial; a.collection = io.collection;
   a.slot_table = io.slot_table;
   RC(launch_reverse_step(a, st));

@@ -57,12 +57,14 @@ __host__ __device__ __forceinline__ TfKey jax_split_at(TfKey k, uint32_t c, uint
 __device__ __forceinline__ float jax_u01(uint32_t bits) { return __uint_as_float((bits >> 9) | 0x3F800000u) - 1.0f; }
 
 __device__ __forceinline__ float jax_uniform_from_bits(uint32_t bits, float lo, float hi) {
-  const float v = jax_u01(bits) * (hi - lo) + lo;      // mul then add, rounded separately: rng_jax.hip builds with -ffp-contract=off
+#pragma clang fp contract(off)                          // mul then add, rounded separately (like the restatement)
+  const float v = jax_u01(bits) * (hi - lo) + lo;
   return fmaxf(lo, v);
 }
 
 // XLA ErfInv (float32): w = -log((1-x)(1+x)); two degree-8 polynomials in w - 2.5 / sqrt(w) - 3 (Giles 2010)
 __device__ __forceinline__ float xla_erfinv_f32(float x) {
+#pragma clang fp contract(off)
   float w = -logf((1.0f - x) * (1.0f + x));
   const bool lt = w < 5.0f;
   w = lt ? w - 2.5f : sqrtf(w) - 3.0f;

@@ -190,6 +190,12 @@ struct ReverseStepArgs {
   const float* infill_samples = nullptr;  // [B][S][C] or null
   const float* infill_masks = nullptr;
   const float* infill_z_in = nullptr;
+  // jax.random streams drawn in the kernel (rng_threefry.h): per-iteration keys [iters][2], row (tf_t0 - t); the state
+  // is the window [sample_offset*S*C, ...) of a global array of tf_n_total elements.  Overrides Philox when set.
+  const uint32_t* tf_noise_keys = nullptr;
+  const uint32_t* tf_infill_keys = nullptr;
+  int64_t tf_n_total = 0;
+  int tf_t0 = 0;
   bf16_t* x_bf16 = nullptr;           // [B*S][Cp] next network input (zero padded)
   float* metrics_partial = nullptr;   // [T][B][3] (grad, step, noise) sums over c of sqrt(sum_s v^2 + 1e-10)
   float* collection = nullptr;        // [41][B][S][C] or null

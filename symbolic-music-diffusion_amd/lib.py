@@ -39,7 +39,8 @@ class SampleIO(C.Structure):
     _fields_ = [("x", c_void), ("t_ptr", c_void), ("z_in", c_void), ("seed_lo", c_u32), ("seed_hi", c_u32),
                 ("sample_offset", c_u32), ("infill_samples", c_void), ("infill_masks", c_void),
                 ("infill_z_in", c_void), ("metrics_partial", c_void), ("collection", c_void),
-                ("slot_table", c_void)]
+                ("slot_table", c_void), ("tf_noise_keys", c_void), ("tf_infill_keys", c_void), ("tf_n_total", c_i64),
+                ("tf_t0", c_i32)]
 
 
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.

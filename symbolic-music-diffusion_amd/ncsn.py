@@ -250,37 +250,32 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     explicit = noises is not None or infill_noises is not None
     jax_mode = isinstance(rng, ThreefryKey) and not explicit
     if jax_mode:
+        # the reference's own draws: the three splits per iteration (:329,342,360) are unrolled on the host into key
+        # tables; the fused reverse step reads row (t_hi - t) on the device and evaluates jax.random.normal for its
+        # elements of the global (N, S, C) array in place of its Philox draw
         per = int(np.prod(init.shape[1:]))
         n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
         ik, nk = _jr.sampler_key_tables(rng, len(steps))
-        # row i of the tables belongs to the i-th iteration, i.e. t = t_hi - i: index (t_hi - t) on the device
         nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
         ik_d = torch.from_numpy(ik.view(np.int32).copy()).to(dev) if infill else None
-        zbuf = torch.zeros_like(x)
-        izbuf = torch.zeros_like(x) if infill else None
-        io.z_in = zbuf.data_ptr()
-        io.infill_z_in = None if izbuf is None else izbuf.data_ptr()
-
-        def jax_step():
-            _jr.fill_normal_from_table(zbuf, nk_d, t_ptr, t_hi + 1, n_total=n_glob, offset=sample_offset * per)
-            if izbuf is not None:
-                _jr.fill_normal_from_table(izbuf, ik_d, t_ptr, t_hi + 1, n_total=n_glob, offset=sample_offset * per)
-            eng.sample_step(io)
-
+        io.tf_noise_keys = nk_d.data_ptr()
+        io.tf_infill_keys = None if ik_d is None else ik_d.data_ptr()
+        io.tf_n_total = n_glob
+        io.tf_t0 = t_hi
         if use_graph and len(steps) > 1:
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
-                jax_step()                               # warm-up (also t = t_hi)
+                eng.sample_step(io)                      # warm-up (also t = t_hi)
             torch.cuda.current_stream(dev).wait_stream(s)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                jax_step()
+                eng.sample_step(io)
             for _ in steps[1:]:
                 graph.replay()
         else:
             for _ in steps:
-                jax_step()
+                eng.sample_step(io)
     elif explicit:
         zbuf = torch.zeros_like(x)
         izbuf = torch.zeros_like(x) if infill else None

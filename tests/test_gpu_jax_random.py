@@ -73,6 +73,20 @@ def test_device_normal_reproduces_jax_documentation_values(dev):
         assert abs(n1(s) - want) < 5e-7
 
 
+def test_device_key_table_indexed_by_a_device_counter(dev):
+    """smd_threefry_normal with key_table / idx_ptr: the key is picked on the device (row idx_add + idx_mul * *idx_ptr)."""
+    import smd_amd.jax_random as J
+    ik, nk = J.sampler_key_tables(J.PRNGKey(9), 5)
+    table = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
+    t_ptr = torch.tensor([0], dtype=torch.int32, device=dev)
+    out = torch.empty(3, 7, device=dev)
+    for it in range(5):
+        t_ptr.fill_(4 - it)                                   # the sampler's t runs 4, 3, ... ; row = 4 - t = iteration
+        J.fill_normal_from_table(out, table, t_ptr, 5)
+        want = J.normal(J.ThreefryKey(int(nk[it, 0]), int(nk[it, 1])), (3, 7), dev)
+        assert torch.equal(out, want)
+
+
 def _model(C=42, L=2, K=1):
     from test_gpu_engine import make
     return make(C=C, L=L, K=K)
