@@ -43,12 +43,20 @@ template <int... Es>
 __device__ __forceinline__ void stage_tile(const f32x16_t& acc, float* stage, int row0, int col, IntSeq<Es...>) {
   ((stage[(row0 + (Es & 3) + 8 * (Es >> 2)) * STAGE_LD + col] = acc[Es]), ...);
 }
+template <int... Es>
+__device__ __forceinline__ void stage_tile_add(const f32x16_t& acc, float* stage, int row0, int col, IntSeq<Es...>) {
+  ((stage[(row0 + (Es & 3) + 8 * (Es >> 2)) * STAGE_LD + col] += acc[Es]), ...);
+}
 
 // NS = number of LDS K-tile buffers.  2: one tile prefetched ahead (MFMA-bound shapes, 64 KiB at BM = 128).
 // 4 (BM <= 64, K >= 512): three tiles in flight -- the skinny-output GEMMs of the 128-wide encoder run one
 // workgroup per CU with 4 MFMAs per wave per K-tile, so a 2-deep pipeline is bound by the DMA latency.
-template <int BM, int NS>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda,
+// KG = K-groups inside the workgroup (1 or 2): with KG = 2 the workgroup has 8 waves, wave group kg stages and
+// multiplies the K-tiles kt*2 + kg in its own LDS ring, both groups share the barriers, and the two partial tiles
+// are added in the epilogue's LDS stage (fixed order).  For the skinny-output GEMMs (one 32-row tile per CU) that is
+// twice the DMA in flight and two waves per SIMD for the same output tile.
+template <int BM, int NS, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void gemm_nt_kernel(const bf16_t* __restrict__ A, int lda,
                                                       const bf16_t* __restrict__ Bt, int ldb, int M, int N, int K,
                                                       int tiles_n, int nwg, int vec_epilogue, GemmEpilogue ep) {
   constexpr int WM = BM >= 64 ? 2 : 1;            // waves along M
@@ -60,7 +68,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
   constexpr int A_PIECES = BM / 32;               // 1-KiB DMA pieces per wave per K-tile
   constexpr int SROWS = BM < 64 ? BM : 64;        // rows staged per epilogue pass
   constexpr int STAGE_BYTES = SROWS * STAGE_LD * 4;
-  constexpr int SMEM_BYTES = NS * BUF_BYTES > STAGE_BYTES ? NS * BUF_BYTES : STAGE_BYTES;
+  constexpr int SMEM_BYTES = NS * KG * BUF_BYTES > STAGE_BYTES ? NS * KG * BUF_BYTES : STAGE_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   // ---- XCD-aware bijective remap (block b runs on XCD b % 8; give each XCD a contiguous band)
@@ -72,7 +80,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kg = KG == 1 ? 0 : w8 >> 2;           // K-group of this wave
+  const int w = KG == 1 ? w8 : (w8 & 3);          // wave index inside its group
   const int wr = w / WN, wc = w % WN;
 
   // ---- per-lane DMA source pointers. A: wave w piece j covers LDS rows (w*A_PIECES+j)*8 .. +8,
@@ -94,12 +104,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
     b_src[j] = Bt + (size_t)gb * ldb + gk;
   }
 
-  auto issue_tile = [&](int kt, int buf) {
-    unsigned char* base = smem + buf * BUF_BYTES;
+  auto issue_tile = [&](int kt, int buf) {        // step kt of this K-group = K-tile kt*KG + kg
+    unsigned char* base = smem + (buf * KG + kg) * BUF_BYTES;
+    const int ko = (kt * KG + kg) * BK;
 #pragma unroll
-    for (int j = 0; j < A_PIECES; ++j) glds16(a_src[j] + kt * BK, base + (w * A_PIECES + j) * 1024);
+    for (int j = 0; j < A_PIECES; ++j) glds16(a_src[j] + ko, base + (w * A_PIECES + j) * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(b_src[j] + kt * BK, base + A_BYTES + (w * 4 + j) * 1024);
+    for (int j = 0; j < 4; ++j) glds16(b_src[j] + ko, base + A_BYTES + (w * 4 + j) * 1024);
   };
 
   // ---- fragment read offsets (bytes) within a buffer
@@ -119,11 +130,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  const int nk = K / BK;
+  const int nk = K / (BK * KG);
   auto compute_tile = [&](int buf) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* tb = smem + buf * BUF_BYTES;
+    const unsigned char* tb = smem + (buf * KG + kg) * BUF_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int coff = ((ks * 2 + kh) ^ fsw) << 4;
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
   for (int p = 0; p < PASSES; ++p) {
     if (p > 0) __syncthreads();
     // rows [p*SROWS, (p+1)*SROWS) of the block tile: wave rows wr*WTM .. +WTM
-    if (wr * WTM >= p * SROWS && wr * WTM < (p + 1) * SROWS) {
+    if (kg == 0 && wr * WTM >= p * SROWS && wr * WTM < (p + 1) * SROWS) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -187,11 +198,22 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
                      Seq16{});
     }
     __syncthreads();
+    if constexpr (KG == 2) {              // the second K-group adds its partial tile (same lane -> element mapping)
+      if (kg == 1 && wr * WTM >= p * SROWS && wr * WTM < (p + 1) * SROWS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            stage_tile_add(acc[i][j], stage, wr * WTM - p * SROWS + i * 32 + 4 * kh, wc * WTN + j * 32 + (lane & 31),
+                           Seq16{});
+      }
+      __syncthreads();
+    }
     const int c4 = (tid & 31) * 4;
     const int col = n0 + c4;
 #pragma unroll
-    for (int i = 0; i < SROWS / 8; ++i) {
-      const int rs = (tid >> 5) + 8 * i;
+    for (int i = 0; i < SROWS / (8 * KG); ++i) {
+      const int rs = (tid >> 5) + 8 * KG * i;
       const int row = m0 + p * SROWS + rs;
       if (row < M && col < N) {
         const float4 a4 = *reinterpret_cast<const float4*>(stage + rs * STAGE_LD + c4);
@@ -201,12 +223,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const bf16_t* __restrict__
   }
 }
 
-template <int BM, int NS>
+template <int BM, int NS, int KG = 1>
 void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K, int vec, const GemmEpilogue& ep,
                hipStream_t st) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, NS>), dim3(nwg), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, vec, ep);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, NS, KG>), dim3(nwg), dim3(256 * KG), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, vec, ep);
 }
 
 }  // namespace
@@ -214,7 +236,7 @@ void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N
 // process-wide kernel-selection knobs (smd_set_tuning in the C-ABI)
 namespace {
 struct Knob { const char* key; int value; };
-Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 1}};
+Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 1}, {"gemm_nt_kg", 1}};
 }
 int smd_tuning_set(const char* key, int value) {
   for (Knob& k : g_knobs)
@@ -245,7 +267,10 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
   const long wg64 = (long)((M + 63) / 64) * tiles_n;
   const bool deep = K >= 8 * BK && smd_tuning_get("gemm_nt_deep");
   if (M <= 32 || !(wg128 >= 512 || wg64 >= 256 || M <= 64)) {
-    if (deep) launch_bm<32, 4>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+    // K >= 1024: two K-groups of four waves per workgroup (A/B: 8-18 % over one group with a 4-deep ring; deeper rings
+    // -- 7 stages, or 2 groups x 4 stages -- gain nothing: the step time follows the LDS-DMA landing cadence)
+    if (deep && K >= 16 * BK && K % (2 * BK) == 0 && smd_tuning_get("gemm_nt_kg")) launch_bm<32, 3, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+    else if (deep) launch_bm<32, 4>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
     else launch_bm<32, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   } else if (wg128 >= 512) {
     launch_bm<128, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);

@@ -169,4 +169,6 @@ def test_sample_api_threefry_init_and_sharding():
     assert close_normal(coll[0].cpu().numpy(), want_init)                   # collection[0] = init (:323, :539-540)
     assert torch.isfinite(gen).all() and float(gen.abs().max()) <= 1.0 + 1e-5
     half, _, _ = N.sample(model, BETAS, rng, (32, 42), num_samples=2, sampling="ddpm", sample_offset=2, global_num_samples=4)
-    assert float((half - gen[2:]).abs().max()) < 2e-3         # 1000 steps; rows ride in a different batch size
+    # 1000 steps; the rows ride in a different batch size, i.e. through different GEMM tilings (K-split order):
+    # 1e-7 differences per step, amplified by the walk; a different stream would differ by O(1)
+    assert float((half - gen[2:]).abs().max()) < 1e-2

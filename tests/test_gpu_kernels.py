@@ -58,7 +58,8 @@ def test_probe_tr_read(L, dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 42, 192), (1000, 4096, 512),
-                                   (8192, 2048, 2048), (64, 512, 2048)])
+                                   (8192, 2048, 2048), (64, 512, 2048), (512, 128, 2048), (96, 200, 1024),
+                                   (8192, 128, 2048)])      # the last three: 32-row tiles with two K-groups per workgroup
 def test_gemm_nt_plain(L, dev, M, N, K):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     A = bf(torch.randn(M, K, generator=g))

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--variants", type=lambda t: [int(x) for x in t.split(",")], default=[0, 1])
     ap.add_argument("--shapes", default="8192x2048x2048")
     ap.add_argument("--mlp", action="store_true", help="fused encoder MLP half-layer")
+    ap.add_argument("--kg-ab", action="store_true", help="A/B of the two-K-group skinny NT GEMM")
     ap.add_argument("--deep-ab", action="store_true", help="A/B of the 2- vs 4-stage skinny NT GEMM")
     ap.add_argument("--ln-ab", action="store_true", help="interleaved A/B of the LayerNorm backward kernels")
     ap.add_argument("--tn128", action="store_true", help="split-K sweep of the 128-wide wgrad kernel")
@@ -78,6 +79,28 @@ def main():
                                                       su.data_ptr() if save else None, st))
             rec(f"mlp_block_fwd(save={save},ablate={var})", [R, 128, M], timeit(f, a.reps), flops=4.0 * R * 128 * M)
         lib.check(L.smd_set_tuning(b"mlp_variant", 0))
+        return
+    if a.kg_ab:
+        for (M, N, K) in [(R, 128, 2048), (R, 128, 1024), (R, 42, 2048), (2048, 128, 2048)]:
+            A, Bt = bf(M, K), bf(N, K)
+            bias = torch.zeros(N, device=dev)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            res32, out32 = torch.randn(M, N, device=dev), torch.empty(M, N, device=dev)
+            fb = lambda: lib.check(L.smd_gemm_bf16_nt(A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), 0, None, 0,
+                                                      None, 0, out.data_ptr(), N, st))
+            fr = lambda: lib.check(L.smd_gemm_bf16_nt(A.data_ptr(), K, Bt.data_ptr(), K, M, N, K, bias.data_ptr(), 0,
+                                                      res32.data_ptr(), N, out32.data_ptr(), N, None, 0, st))
+            for name, f in (("b", fb), ("r", fr)):
+                modes = {0: "1 group x 4 stages", 1: "2 K-groups x 3 stages"}
+                res = {m: [] for m in modes}
+                for _ in range(5):
+                    for mode in modes:
+                        lib.check(L.smd_set_tuning(b"gemm_nt_kg", mode))
+                        res[mode].append(timeit(f, a.reps))
+                for mode in modes:
+                    rec(f"kg_ab:{modes[mode]}:{name}", [M, N, K], sorted(res[mode])[2],
+                        flops=2.0 * M * N * K, bytes_=2.0 * (M * K + N * K + M * N))
+        lib.check(L.smd_set_tuning(b"gemm_nt_kg", 1))
         return
     if a.deep_ab:
         for (M, N, K) in [(R, 128, 2048), (R, 128, 512), (R, 384, 128), (R, 128, 128), (R, 512, 2048), (256, 4096, 512)]:
