@@ -147,10 +147,10 @@ template <int D, bool XBF> struct WideRow {
 // shift) from the L2 for every row -- 4x the bytes of the row itself.  Here a workgroup of 8 waves owns one row group
 // (a sample's rows with per-sample FiLM, else 32 rows), keeps the parameters in LDS and walks the group's rows
 // (SGPR row bases, all of a row's loads issued up front).  FS: FiLM + swish (ResBlock norms) or neither.
-template <int D, bool XBF, bool FS>
-__global__ __launch_bounds__(512) void layernorm_fwd_wide_kernel(LnArgs a, int group_rows) {
+template <int D, bool XBF, bool FS, int NW>
+__global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, int group_rows) {
   typedef RowLayout<D> L;
-  constexpr int NV = L::NV, NW = 8;
+  constexpr int NV = L::NV;
   __shared__ __attribute__((aligned(16))) float prm[FS ? 4 : 2][D];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void layernorm_fwd_wide_kernel(LnArgs a, int g
                            FS ? a.film_shift + (size_t)frow * a.ld_film : nullptr};
 #pragma unroll
     for (int q = 0; q < (FS ? 4 : 2); ++q)
-      for (int c = threadIdx.x * 4; c < D; c += 2048)
+      for (int c = threadIdx.x * 4; c < D; c += 256 * NW)
         *reinterpret_cast<float4*>(&prm[q][c]) = *reinterpret_cast<const float4*>(src[q] + c);
   }
   __syncthreads();
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(512) void layernorm_fwd_wide_kernel(LnArgs a, int g
 #pragma unroll
       for (int e = 0; e < 4; ++e) t[e] = f2bf(y[e]);
       *reinterpret_cast<bf16x4_t*>(orow + (l4 + k * 256)) = t;
+      __builtin_amdgcn_sched_barrier(0);      // keep the LDS parameter reads of later chunks from being hoisted (VGPRs)
     }
   }
 }
@@ -862,7 +863,11 @@ template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
     const int gr = (a.film_scale && !a.t_ptr) ? a.rows_per_sample : 32;
     if (smd_tuning_get("ln_fwd_wide") && (fs || plain) && gr >= 8) {
       const int ng = (a.rows + gr - 1) / gr;
-#define SMD_FW(XB, FS_) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_>), dim3(ng), dim3(512), 0, st, a, gr)
+#define SMD_FW(XB, FS_)                                                                                               \
+  do {                                                                                                               \
+    if (smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16>), dim3(ng), dim3(1024), 0, st, a, gr); \
+    else hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 8>), dim3(ng), dim3(512), 0, st, a, gr);            \
+  } while (0)
       if (a.x_bf16) { if (fs) SMD_FW(true, true); else SMD_FW(true, false); }
       else          { if (fs) SMD_FW(false, true); else SMD_FW(false, false); }
 #undef SMD_FW
