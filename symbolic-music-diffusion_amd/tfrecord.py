@@ -117,6 +117,8 @@ def _feature(buf: bytes):
             return [v for f2, _w, v in _fields(val) if f2 == 1]
         if fno == 2:                                            # FloatList: packed (LEN) or repeated fixed32
             parts = [np.frombuffer(v, dtype="<f4") for f2, _w, v in _fields(val) if f2 == 1]
+            if not parts:
+                return np.zeros((0,), np.float32)
             return np.concatenate(parts) if len(parts) != 1 else parts[0].copy()
         if fno == 3:                                            # Int64List: packed varints or repeated varint
             out: List[int] = []

@@ -136,3 +136,62 @@ def test_open_dataset_from_tfrecords_follows_the_reference_order(tmp_path):
                                    out_channels=16)
     assert inv.dtype == np.float64 and inv.shape == (20, 4, 16)
     assert np.allclose(inv[..., slice_idx], kept_t, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- property tests
+from hypothesis import given, settings, strategies as st_  # noqa: E402
+import hypothesis.extra.numpy as hnp  # noqa: E402
+
+_names = st_.text(alphabet="abcdefghijklmnopqrstuvwxyz_0123456789", min_size=1, max_size=12)
+_floats = hnp.arrays(np.float32, st_.integers(0, 40), elements=st_.floats(-1e6, 1e6, width=32))
+_ints = hnp.arrays(np.int64, st_.integers(0, 40), elements=st_.integers(-(2 ** 62), 2 ** 62))
+_bytes = st_.lists(st_.binary(max_size=20), max_size=4)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st_.dictionaries(_names, st_.one_of(_floats, _ints, _bytes), max_size=5))
+def test_example_round_trip_and_protobuf_agreement_property(features):
+    """Any Example our writer produces is read back identically by our parser AND by the protobuf runtime."""
+    import smd_amd.tfrecord as T
+    raw = T.make_example(features)
+    got = T.parse_example(raw)
+    ex = _tf_example_classes()()
+    ex.ParseFromString(raw)
+    assert set(got) == set(features) == set(ex.features.feature)
+    for k, v in features.items():
+        f = ex.features.feature[k]
+        if isinstance(v, np.ndarray) and v.dtype == np.float32:
+            assert np.array_equal(got[k], v) and np.array_equal(np.asarray(f.float_list.value, np.float32), v)
+        elif isinstance(v, np.ndarray):
+            assert np.array_equal(got[k], v) and list(f.int64_list.value) == v.tolist()
+        else:
+            assert list(got[k]) == list(v) if len(v) else len(got[k]) == 0
+            assert list(f.bytes_list.value) == list(v)
+    # and the runtime's own serialisation of the same message parses to the same features
+    again = T.parse_example(ex.SerializeToString())
+    for k, v in features.items():
+        if isinstance(v, np.ndarray):
+            assert np.array_equal(again[k], v)
+
+
+_dtypes = st_.sampled_from([np.float32, np.float64, np.int32, np.int64, np.uint8, np.bool_, np.float16])
+
+
+@settings(max_examples=60, deadline=None)
+@given(st_.recursive(
+    st_.one_of(st_.integers(-2 ** 31, 2 ** 31), st_.floats(allow_nan=False), st_.booleans(),
+               _dtypes.flatmap(lambda d: hnp.arrays(d, hnp.array_shapes(min_dims=0, max_dims=3, max_side=5)))),
+    lambda children: st_.dictionaries(_names, children, max_size=4), max_leaves=12))
+def test_flax_msgpack_round_trip_property(tree):
+    import smd_amd.flax_io as FI
+
+    def same(a, b):
+        if isinstance(a, dict):
+            return isinstance(b, dict) and set(a) == set(b) and all(same(a[k], b[k]) for k in a)
+        if isinstance(a, np.ndarray):
+            return isinstance(b, np.ndarray) and a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+        return a == b and type(a) is type(b)
+
+    if not isinstance(tree, dict):
+        tree = {"leaf": tree}
+    assert same(tree, FI.from_bytes(FI.to_bytes(tree)))
