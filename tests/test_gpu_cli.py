@@ -105,7 +105,8 @@ def test_config1_dense_ddpm_end_to_end(tmp_path):
         D.save(x, str(tmp_path / "ds" / f"{split}.pkl"))
     flags = ["--flagfile=configs/ddpm-mel-1seq-512.cfg", f"--dataset={tmp_path / 'ds'}", f"--model_dir={tmp_path / 'model'}",
              "--batch_size=8", "--num_layers=2", "--mlp_dims=256"]
-    run("train_ncsn.py", *flags, "--epochs=12", "--logging_freq=1", "--snapshot_freq=1000", "--learning_rate=2e-3")
+    run("train_ncsn.py", *flags, "--epochs=12", "--logging_freq=1", "--snapshot_freq=1000", "--learning_rate=2e-3",
+        "--ckpt_format=flax")                                               # --ema comes from the config: EMA tree in the file
     rows = [json.loads(l) for l in open(tmp_path / "model" / "train" / "scalars.jsonl")]
     loss = [r["value"] for r in rows if r["tag"] == "loss"]
     assert len(loss) == 96 and np.isfinite(loss).all()                  # 12 epochs x 8 batches
@@ -115,7 +116,13 @@ def test_config1_dense_ddpm_end_to_end(tmp_path):
     lr = [r["value"] for r in rows if r["tag"] == "lr"]
     assert abs(lr[0] - 2e-3) < 1e-9
     out = tmp_path / "samples"
-    run("sample_ncsn.py", *flags, "--sample_size=8", f"--sampling_dir={out}")
+    import smd_amd.flax_io as FI
+    ck = [f for f in sorted(os.listdir(tmp_path / "model")) if f.startswith("checkpoint_")]
+    sd = FI.read_file(str(tmp_path / "model" / ck[-1]))
+    assert list(sd["1"]["params"]) == ["Dense_0", "DenseFiLM_1", "DenseResBlock_2", "DenseFiLM_3", "DenseResBlock_4", "LayerNorm_5", "Dense_6"]
+    w, we = sd["0"]["target"]["params"]["Dense_0"]["kernel"], sd["1"]["params"]["Dense_0"]["kernel"]
+    assert w.shape == (512, 256) and not np.array_equal(w, we) and abs(float(sd["1"]["mu"]) - 0.999) < 1e-6   # EMA lags the weights
+    run("sample_ncsn.py", *flags, "--sample_size=8", f"--sampling_dir={out}", "--sample_ema=true")
     gen = D.load(str(out / "ncsn" / "generated.pkl"))
     coll = D.load(str(out / "ncsn" / "collection.pkl"))
     assert gen.shape == (8, 512) and coll.shape == (41, 8, 512) and np.isfinite(gen).all()
