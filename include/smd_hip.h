@@ -13,7 +13,9 @@
  *     a thread-local message for the last non-zero return.
  *   - bf16 buffers are uint16 storage (`smd_bf16`).  GEMM operands are row-major with the
  *     contraction dimension padded to a multiple of 64 (zero filled).
- *   - no global mutable state; entry points are re-entrant and stream-ordered.
+ *   - entry points are re-entrant and stream-ordered.  The only process-wide mutable state is the kernel-selection
+ *     table behind smd_set_tuning() (benchmark A/B knobs; the defaults are the shipped paths) and a thread-local
+ *     error string; everything else lives in the caller's buffers or in an smd_engine handle.
  */
 #ifndef SMD_HIP_H_
 #define SMD_HIP_H_
@@ -128,7 +130,10 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
 /* process-wide kernel-selection knob for benchmark A/B runs (defaults = fast paths).
  * "gemm_nt256": 1 = large Dense GEMMs use the 256x256 8-phase kernel (default), 0 = 128-wide tiles only,
  *               2 = every shape with M,N % 256 == 0 and K % 128 == 0 (tests);
- * "gemm_nt256_variant": schedule variant of that kernel (0 default);
+ * "gemm_nt256_variant": schedule variant of that kernel, 0 (default) .. 3, all computing the same result; the
+ *               ablation variants used by tools/kbench.py exist only in a -DSMD_ABLATIONS build;
+ * "ln_bwd_narrow": 0 (default) = the 128-wide LayerNorm backward runs on the one-row-per-wave kernel, 1 = the
+ *               16-lanes-per-row kernel (faster, but not bitwise repeatable next to the side stream: DESIGN.md 6);
  * "gemm_tn256": 1 = 2048-wide weight gradients use the 256x256 8-phase kernel (default), 0 = 128-wide tiles,
  *               2 = also on small grids (tests). */
 int smd_set_tuning(const char* key, int value);
@@ -205,8 +210,9 @@ int smd_threefry_normal(float* out, int64_t n_total, int64_t offset, int64_t cou
 int smd_threefry_randint(int32_t* out, int64_t n_total, int64_t offset, int64_t count, uint32_t k0, uint32_t k1,
                          int32_t minval, int32_t maxval, void* stream);
 int smd_cast_pad_bf16(const float* in, int rows, int cols, smd_bf16* out, int ld_out, void* stream);
-/* one reverse step on explicit eps_hat (the elementwise part of utils/ebm_utils.py:327-394) */
-int smd_ddpm_reverse_step(float* x, const float* eps_hat, int B, int S, int C, const float* coef,
+/* one reverse step on explicit eps_hat (the elementwise part of utils/ebm_utils.py:327-394); coef is the [T][8]
+ * table, *t_ptr outside [0, T) makes the call a no-op */
+int smd_ddpm_reverse_step(float* x, const float* eps_hat, int B, int S, int C, const float* coef, int T,
                           const int32_t* t_ptr, const float* z_in, uint32_t seed_lo, uint32_t seed_hi,
                           uint32_t sample_offset, float* metrics_partial, float* collection,
                           const int32_t* slot_table, void* stream);

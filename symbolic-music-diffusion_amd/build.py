@@ -20,6 +20,10 @@ HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.
            os.path.join("..", "..", "include", "smd_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+# SMD_ABLATIONS=1 in the environment: also compile the kernel-ablation variants (wrong results by construction; only
+# tools/kbench.py --gemm-ab uses them).  The shipped library never contains them.
+if os.environ.get("SMD_ABLATIONS") == "1":
+    FLAGS.append("-DSMD_ABLATIONS")
 
 
 # per-file code generation switches

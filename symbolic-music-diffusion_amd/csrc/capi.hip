@@ -255,11 +255,11 @@ int smd_threefry_randint(int32_t* out, int64_t n_total, int64_t offset, int64_t 
 int smd_cast_pad_bf16(const float* in, int rows, int cols, smd_bf16* out, int ld_out, void* stream) {
   return launch_cast_pad_bf16(in, rows, cols, B(out), ld_out, S(stream));
 }
-int smd_ddpm_reverse_step(float* x, const float* eps_hat, int Bn, int Sn, int C, const float* coef, const int32_t* t_ptr,
+int smd_ddpm_reverse_step(float* x, const float* eps_hat, int Bn, int Sn, int C, const float* coef, int T, const int32_t* t_ptr,
                           const float* z_in, uint32_t lo, uint32_t hi, uint32_t off, float* metrics_partial,
                           float* collection, const int32_t* slot_table, void* stream) {
   ReverseStepArgs a;
-  a.x = x; a.eps_hat = eps_hat; a.B = Bn; a.S = Sn; a.C = C; a.Cp = C; a.coef = coef; a.t_ptr = t_ptr; a.z_in = z_in;
+  a.x = x; a.eps_hat = eps_hat; a.B = Bn; a.S = Sn; a.C = C; a.Cp = C; a.coef = coef; a.T = T; a.t_ptr = t_ptr; a.z_in = z_in;
   a.key = RngKey{lo, hi}; a.sample_offset = off; a.metrics_partial = metrics_partial; a.collection = collection;
   a.slot_table = slot_table;
   return launch_reverse_step(a, S(stream));

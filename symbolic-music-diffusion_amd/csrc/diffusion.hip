@@ -138,6 +138,7 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
   const int b = blockIdx.x;
   const int ct = threadIdx.x & 127, rg = threadIdx.x >> 7;
   const int t = *a.t_ptr;
+  if (t < 0 || t >= a.T) return;          // walked past t = 0 (or a bad timestep): a no-op, t is not advanced either
   const float* cf = a.coef + (size_t)t * 8;
   const float sqrt_recip = cf[0], sqrt_m1 = cf[1], mu1 = cf[2], mu2 = cf[3], sigma = cf[4];
   const float sqrt_ap = cf[6], sqrt_1m = cf[7];
@@ -274,6 +275,16 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
       a.metrics_partial[((size_t)t * a.B + b) * 3 + threadIdx.x] = v;
     }
   }
+  // *t_advance = t - 1 by the LAST workgroup to get here (every workgroup read t at its top, i.e. before its own
+  // arrival): the timestep decrement of the captured sampling step without a launch of its own.  `arrive` is zero
+  // between launches (the last arriver resets it with a device-scope atomic).
+  if (a.t_advance && threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_exchange(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.t_advance, t - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 __global__ void advance_t_kernel(int* t_ptr) { *t_ptr -= 1; }
@@ -341,6 +352,8 @@ int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && (!a.x_bf16 || a.Cp >= a.C), "reverse_step: bad shape");
   SMD_ARG_CHECK((a.infill_masks != nullptr) == (a.infill_samples != nullptr), "reverse_step: infill needs samples and masks");
   SMD_ARG_CHECK(!a.collection || a.slot_table, "reverse_step: collection needs slot_table");
+  SMD_ARG_CHECK(a.T > 0, "reverse_step: T=%d (number of timesteps: bounds the coefficient table)", a.T);
+  SMD_ARG_CHECK(!a.t_advance || a.arrive, "reverse_step: t_advance needs the arrival counter");
   SMD_ARG_CHECK(!(a.tf_noise_keys || a.tf_infill_keys) || (a.tf_n_total >= (int64_t)(a.sample_offset + a.B) * a.S * a.C &&
                                                             a.tf_n_total <= (1ll << 32)),
                 "reverse_step: tf_n_total=%lld must cover this rank's window and be <= 2^32", (long long)a.tf_n_total);

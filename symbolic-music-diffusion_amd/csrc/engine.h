@@ -213,6 +213,7 @@ class SmdEngine {
     size_t tn_slab_elems = 0;
     float* norm_partial = nullptr;        // [1024]
     bf16_t* zero_page = nullptr;          // [128]
+    unsigned* step_arrive = nullptr;      // [64] arrival counter of the fused reverse step
     bf16_t* tn_scratch = nullptr;         // fallback wgrad transposes
     size_t tn_scratch_elems = 0;
   } W;

@@ -237,6 +237,7 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
   Carver c{reinterpret_cast<char*>(base)};
   Work t;
   t.zero_page = c.take<bf16_t>(128);
+  t.step_arrive = c.take<unsigned>(64);               // arrival counter of the fused reverse step (zeroed with the workspace)
   t.x_bf16 = c.take<bf16_t>(R * Cp_);
   t.pe = c.take<float>((size_t)S * E);
   t.pred = c.take<float>(R * C);
@@ -767,6 +768,6 @@ int SmdEngine::sample_step(const SampleStepIO& io, hipStream_t st) {
   a.tf_noise_keys = io.tf_noise_keys; a.tf_infill_keys = io.tf_infill_keys; a.tf_n_total = io.tf_n_total; a.tf_t0 = io.tf_t0;
   a.x_bf16 = W.x_bf16; a.metrics_partial = io.metrics_partial; a.collection = io.collection;
   a.slot_table = io.slot_table;
-  RC(launch_reverse_step(a, st));
-  return launch_advance_t(io.t_ptr, st);
+  a.t_advance = io.t_ptr; a.arrive = W.step_arrive;      // *t_ptr -= 1 by the step's last workgroup (no launch of its own)
+  return launch_reverse_step(a, st);
 }

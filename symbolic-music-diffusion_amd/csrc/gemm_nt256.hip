@@ -310,18 +310,27 @@ int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M
   const int tiles_m = M / TM, tiles_n = N / TN;
   const int nwg = tiles_m * tiles_n;
   SMD_ARG_CHECK(smd_epi::oct_ok(ep), "gemm_nt256: epilogue not supported (alignment / alpha / res_bf16 / accumulate)");
+#define SMD_NT256_LAUNCH(V_) hipLaunchKernelGGL(gemm_nt256_kernel<V_>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep)
+  // schedule variants 1..3 compute the same result (A/B runs); the ABLATION variants (bits 4, 8, 32, 64: parts of the
+  // kernel removed, wrong results by construction) exist only in a -DSMD_ABLATIONS build (tools/kbench.py --gemm-ab)
   switch (smd_tuning_get("gemm_nt256_variant")) {
-    case 1: hipLaunchKernelGGL(gemm_nt256_kernel<1>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 2: hipLaunchKernelGGL(gemm_nt256_kernel<2>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 3: hipLaunchKernelGGL(gemm_nt256_kernel<3>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 4: hipLaunchKernelGGL(gemm_nt256_kernel<4>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 8: hipLaunchKernelGGL(gemm_nt256_kernel<8>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 32: hipLaunchKernelGGL(gemm_nt256_kernel<32>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 64: hipLaunchKernelGGL(gemm_nt256_kernel<64>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 96: hipLaunchKernelGGL(gemm_nt256_kernel<96>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    case 12: hipLaunchKernelGGL(gemm_nt256_kernel<12>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
-    default: hipLaunchKernelGGL(gemm_nt256_kernel<0>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep); break;
+    case 0: SMD_NT256_LAUNCH(0); break;
+    case 1: SMD_NT256_LAUNCH(1); break;
+    case 2: SMD_NT256_LAUNCH(2); break;
+    case 3: SMD_NT256_LAUNCH(3); break;
+#ifdef SMD_ABLATIONS
+    case 4: SMD_NT256_LAUNCH(4); break;
+    case 8: SMD_NT256_LAUNCH(8); break;
+    case 12: SMD_NT256_LAUNCH(12); break;
+    case 32: SMD_NT256_LAUNCH(32); break;
+    case 64: SMD_NT256_LAUNCH(64); break;
+    case 96: SMD_NT256_LAUNCH(96); break;
+#endif
+    default:
+      smd_set_error("gemm_nt256: variant %d is not in this build (ablation variants need -DSMD_ABLATIONS)", smd_tuning_get("gemm_nt256_variant"));
+      return -1;
   }
+#undef SMD_NT256_LAUNCH
   SMD_LAUNCH_CHECK();
   return 0;
 }

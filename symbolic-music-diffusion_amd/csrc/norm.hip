@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(LnArgs a) {
 #pragma unroll
   for (int i = 0; i < L::PER_LANE; ++i) y[i] = (x[i] - mean) * rstd * g[i] + b[i];
   if (a.film_scale) {
-    const int frow = a.t_ptr ? *a.t_ptr : row / a.rows_per_sample;
+    const int frow = a.t_ptr ? smd_clamp_t(*a.t_ptr) : row / a.rows_per_sample;
     float sc[L::PER_LANE], sh[L::PER_LANE];
     load_vec<D>(a.film_scale + (size_t)frow * a.ld_film, lane, sc);
     load_vec<D>(a.film_shift + (size_t)frow * a.ld_film, lane, sh);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, i
   int r_end = r_begin + group_rows;
   r_end = r_end < a.rows ? r_end : a.rows;
   {
-    const int frow = FS ? (a.t_ptr ? *a.t_ptr : r_begin / a.rows_per_sample) : 0;
+    const int frow = FS ? (a.t_ptr ? smd_clamp_t(*a.t_ptr) : r_begin / a.rows_per_sample) : 0;
     const float* src[4] = {a.gamma, a.beta, FS ? a.film_scale + (size_t)frow * a.ld_film : nullptr,
                            FS ? a.film_shift + (size_t)frow * a.ld_film : nullptr};
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdDev a) {
   load_vec<D>(a.f.gamma, lane, g);
   load_vec<D>(a.f.beta, lane, b);
   if (film) {
-    const int frow = a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample;
+    const int frow = a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr) : r_begin / a.f.rows_per_sample;
     load_vec<D>(a.f.film_scale + (size_t)frow * a.f.ld_film, lane, sc);
     load_vec<D>(a.f.film_shift + (size_t)frow * a.f.ld_film, lane, sh);
   }
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_wide_kernel(LnBwdDev a) 
   const bool film = a.f.film_scale != nullptr;
   const bool swish = a.f.swish != 0;
   {
-    const int frow = film ? (a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample) : 0;
+    const int frow = film ? (a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr) : r_begin / a.f.rows_per_sample) : 0;
     const float* src[4] = {a.f.gamma, a.f.beta, film ? a.f.film_scale + (size_t)frow * a.f.ld_film : nullptr,
                            film ? a.f.film_shift + (size_t)frow * a.f.ld_film : nullptr};
 #pragma unroll
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
   int r_end = r_begin + a.group_rows;
   r_end = r_end < a.f.rows ? r_end : a.f.rows;
   {
-    const int frow = film ? (a.f.t_ptr ? *a.f.t_ptr : r_begin / a.f.rows_per_sample) : 0;
+    const int frow = film ? (a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr) : r_begin / a.f.rows_per_sample) : 0;
     const float* src[4] = {a.f.gamma, a.f.beta, film ? a.f.film_scale + (size_t)frow * a.f.ld_film : nullptr,
                            film ? a.f.film_shift + (size_t)frow * a.f.ld_film : nullptr};
 #pragma unroll

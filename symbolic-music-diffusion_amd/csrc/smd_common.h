@@ -39,6 +39,9 @@ __device__ __forceinline__ int smd_xcd_band(int bid, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// table row of a device timestep: a sampler walked past t = 0 reads row 0 instead of out of bounds
+__device__ __forceinline__ int smd_clamp_t(int t) { return t < 0 ? 0 : t; }
+
 // ---- scalar math ----
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }

@@ -183,7 +183,9 @@ struct ReverseStepArgs {
   const float* eps_hat = nullptr;     // [B][S][C]
   int B = 0, S = 0, C = 0, Cp = 0, T = 0;
   const float* coef = nullptr;        // [T][8]: sqrt_recip, sqrt_m1, mu1, mu2, sigma, alpha_prod, sqrt_ap, sqrt_1m
-  const int* t_ptr = nullptr;         // device timestep
+  const int* t_ptr = nullptr;         // device timestep; t outside [0, T) makes the launch a no-op
+  int* t_advance = nullptr;           // non-null: the last workgroup stores t - 1 here (normally == t_ptr)
+  unsigned* arrive = nullptr;         // arrival counter for t_advance: zero before the first launch, reset by the kernel
   const float* z_in = nullptr;        // explicit N(0,1) draw [B][S][C] or null -> Philox
   RngKey key{0, 0};
   uint32_t sample_offset = 0;

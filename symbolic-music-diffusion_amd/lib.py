@@ -103,7 +103,7 @@ _SIGS = {
     "smd_threefry_randint": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, C.c_int32, C.c_int32, c_void]),
     "smd_rng_normal": (C.c_int, [c_void, C.c_int, C.c_int, c_u32, c_u32, c_u32, c_u32, c_void]),
     "smd_cast_pad_bf16": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
-    "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void, c_u32,
+    "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_u32,
                                         c_u32, c_u32, c_void, c_void, c_void, c_void]),
     "smd_probe_tr_read": (C.c_int, [c_void, c_void, c_void]),
 }

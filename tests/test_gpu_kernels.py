@@ -528,7 +528,7 @@ def test_reverse_step_kernel(L, dev, C):
         mp = torch.zeros(T, B, 3, device=dev)
         cl = torch.zeros(41, B, Sq, C, device=dev)
         ehd, zd = eh.to(dev), z.to(dev)
-        ck(L, L.smd_ddpm_reverse_step(P(xd), P(ehd), B, Sq, C, P(coefd), P(tp), P(zd), 0, 0, 0,
+        ck(L, L.smd_ddpm_reverse_step(P(xd), P(ehd), B, Sq, C, P(coefd), T, P(tp), P(zd), 0, 0, 0,
                                       P(mp), P(cl), P(slotd), st()))
         torch.cuda.synchronize()
         assert rel(xd, state) < 1e-5

@@ -286,7 +286,7 @@ def main():
     coef = torch.from_numpy(S.reverse_coefficient_table(S.create_noise_schedule(1e-6, 0.01, 1000, "linear"))).to(dev)
     x, eh = torch.randn(256, 32, 512, device=dev), torch.randn(256, 32, 512, device=dev)
     tp = torch.tensor([500], dtype=torch.int32, device=dev)
-    f = lambda: lib.check(L.smd_ddpm_reverse_step(x.data_ptr(), eh.data_ptr(), 256, 32, 512, coef.data_ptr(), tp.data_ptr(),
+    f = lambda: lib.check(L.smd_ddpm_reverse_step(x.data_ptr(), eh.data_ptr(), 256, 32, 512, coef.data_ptr(), 1000, tp.data_ptr(),
                                                   None, 1, 2, 0, None, None, None, st))
     rec("ddpm_reverse_step(philox)", [256, 32, 512], timeit(f, a.reps), bytes_=256 * 32 * 512 * 12.0)
     if a.json:

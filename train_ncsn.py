@@ -123,6 +123,21 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                             (FLAGS.early_stopping and improved and FLAGS.save_ckpt):          # :395-399
                         checkpoint.save_checkpoint(output_dir, (optimizer, ema, early_stop), sampling_step,
                                                    keep=FLAGS.checkpoints_to_keep, fmt=FLAGS.ckpt_format)
+                # early stop is decided BEFORE snapshot sampling, as the reference returns first (:401-403)
+                if comm is not None:                                                           # keep ranks in step
+                    flag = torch.tensor([1.0 if (FLAGS.early_stopping and early_stop.should_stop) else 0.0],
+                                        device=dev)
+                    comm.dist.broadcast(flag, src=0)
+                    stop = bool(flag.item())
+                else:
+                    stop = FLAGS.early_stopping and early_stop.should_stop
+                if stop:                                                                       # :401-403
+                    if rank == 0:
+                        train_writer.flush()
+                        eval_writer.flush()
+                    log.info("EARLY STOP: Ended training after %s epochs.", epoch + 1)
+                    return optimizer
+                if rank == 0:
                     if FLAGS.snapshot_sampling:                                               # :404-414
                         scorenet = ncsn.Model(model.cfg, dev, seed=None)
                         scorenet.replace(ema.params if FLAGS.ema else optimizer.target.params)
@@ -135,16 +150,6 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                         del scorenet
                     train_writer.flush()
                     eval_writer.flush()
-                if comm is not None:                                                           # keep ranks in step
-                    flag = torch.tensor([1.0 if (FLAGS.early_stopping and early_stop.should_stop) else 0.0],
-                                        device=dev)
-                    comm.dist.broadcast(flag, src=0)
-                    stop = bool(flag.item())
-                else:
-                    stop = FLAGS.early_stopping and early_stop.should_stop
-                if stop:                                                                       # :401-403
-                    log.info("EARLY STOP: Ended training after %s epochs.", epoch + 1)
-                    return optimizer
             if FLAGS.max_steps is not None and global_step >= FLAGS.max_steps:                # :492-494
                 return optimizer
     return optimizer
