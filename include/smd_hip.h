@@ -132,8 +132,10 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
  *               2 = every shape with M,N % 256 == 0 and K % 128 == 0 (tests);
  * "gemm_nt256_variant": schedule variant of that kernel, 0 (default) .. 3, all computing the same result; the
  *               ablation variants used by tools/kbench.py exist only in a -DSMD_ABLATIONS build;
- * "ln_bwd_narrow": 0 (default) = the 128-wide LayerNorm backward runs on the one-row-per-wave kernel, 1 = the
- *               16-lanes-per-row kernel (faster, but not bitwise repeatable next to the side stream: DESIGN.md 6);
+ * "ln_bwd_narrow": 1 (default) = the 128-wide LayerNorm backward runs on the 16-lanes-per-row kernel, 0 = one row per wave;
+ * "tn_exclusive_cu": 1 (default) = weight-gradient GEMM workgroups are padded to a CU's whole LDS so that no other
+ *               LDS-using workgroup shares their CU (small LayerNorm-backward workgroups that did lost bitwise
+ *               repeatability), 0 = unpadded (a few % faster, not repeatable);
  * "gemm_tn256": 1 = 2048-wide weight gradients use the 256x256 8-phase kernel (default), 0 = 128-wide tiles,
  *               2 = also on small grids (tests). */
 int smd_set_tuning(const char* key, int value);
@@ -150,6 +152,32 @@ int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, in
 int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
                       const smd_bf16* W1t, const float* b1, const smd_bf16* W2t, const float* b2, int hidden,
                       smd_bf16* save_a2, smd_bf16* save_z1, smd_bf16* save_u, void* stream);
+/* MLP half-layer (models/ncsn.py:163-168) with the hidden dimension split over 4 workgroups per group of 4 / 2 / 1
+ * samples: a quarter of the weight stream per CU.  a2 = ln2(h_mid) in bf16 (smd_attn_block_fwd_ex emits it);
+ * output: four fp32 partial tiles part[k] = part + k*rows*128 with h_out = (p0 + p1) + (p2 + p3) -- quarter 0 carries
+ * b2 + the residual h_res -- to be summed by the consumer (smd_attn_block_fwd_ex / smd_ln128_parts).  hidden % 512 == 0. */
+int smd_mlp_block_fwd_hs(const smd_bf16* a2, const float* h_res, int rows, const smd_bf16* W1t, const float* b1,
+                         const smd_bf16* W2t, const float* b2, int hidden, float* part, void* stream);
+/* backward of that half-layer between ln2 and the residual add, hidden activations recomputed from a2:
+ * u = gelu(a2 W1 + b1) and dz = (dh W2^T) gelu'(.) are written ([rows][hidden] bf16, the operands of the fc2 / fc1 weight
+ * gradients), da2 = dz W1^T leaves as four fp32 partial tiles (summed by smd_ln128_bwd_parts).  W1t [hidden][128]: fc1
+ * forward pack; W2 [hidden][128], W1 [128][hidden]: dgrad packs of fc2 / fc1.  rows % 128 == 0, hidden % 512 == 0. */
+int smd_mlp_block_bwd_hs(const smd_bf16* a2, const smd_bf16* dh, int rows, const smd_bf16* W1t, const smd_bf16* W2,
+                         const smd_bf16* W1, const float* b1, int hidden, smd_bf16* u, smd_bf16* dz, float* part, void* stream);
+/* LayerNorm (D = 128) backward with dout = (p0 + p1) + (p2 + p3) (fp32 partial tiles): dx = LN-backward + dres (nullable)
+ * -> dx_f32 (nullable, may alias dres) / dx_bf16 (nullable); partial [rows/32][2][128] = per-group dgamma / dbeta sums */
+int smd_ln128_bwd_parts(const float* x, const float* parts, int64_t part_stride, int rows, const float* gamma,
+                        const float* dres, float* dx_f32, smd_bf16* dx_bf16, float* partial, void* stream);
+/* x = (p0 + p1) + (p2 + p3) per 128-wide row (parts + k*part_stride); x_out (nullable) <- x, ln_out (nullable) <-
+ * LayerNorm(x) bf16: the encoder's final norm (models/ncsn.py:170) on a hidden-split MLP output */
+int smd_ln128_parts(const float* parts, int64_t part_stride, int rows, const float* gamma, const float* beta, float* x_out,
+                    smd_bf16* ln_out, void* stream);
+/* smd_attn_block_fwd with (a) the input given as four partial tiles (h_parts != NULL: h_in unused; h_comb nullable
+ * receives their sum) and (b) the LayerNorm of the OUTPUT rows (ln2 of the same layer) written as bf16 a2_out (nullable) */
+int smd_attn_block_fwd_ex(const float* h_in, const float* h_parts, int64_t part_stride, float* h_comb, float* h_out, int rows,
+                          const float* gamma, const float* beta, const smd_bf16* Wqkv_t, const float* b_qkv,
+                          const smd_bf16* Wo_t, const float* b_o, int num_heads, const float* gamma2, const float* beta2,
+                          smd_bf16* a2_out, smd_bf16* save_a1, smd_bf16* save_qkv, smd_bf16* save_o, void* stream);
 /* Fused encoder attention half-layer, models/ncsn.py:159-162: h_out = h_in + out(softmax(q k^T / sqrt(d)) v) with
  * q,k,v = Dense(LN(h_in)); 32 tokens per sample, 128-wide stream, num_heads in {4, 8, 16}.  Wqkv_t [384][128]
  * (q | k | v rows), Wo_t [128][128], bf16, contraction contiguous; save_qkv receives the unscaled q. */

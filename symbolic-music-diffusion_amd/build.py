@@ -24,6 +24,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-re
 # tools/kbench.py --gemm-ab uses them).  The shipped library never contains them.
 if os.environ.get("SMD_ABLATIONS") == "1":
     FLAGS.append("-DSMD_ABLATIONS")
+# experiment builds: SMD_EXTRA_DEFS="-DX=1 -DY" adds preprocessor definitions, SMD_LIB_SUFFIX="_tag" names the output
+# csrc/libsmd_hip_tag.so (objects under csrc/build_tag/); lib.py loads that library when SMD_LIB_SUFFIX is set
+FLAGS += [f for f in os.environ.get("SMD_EXTRA_DEFS", "").split() if f]
+_SUFFIX = os.environ.get("SMD_LIB_SUFFIX", "")
+LIB_PATH = os.path.join(CSRC, f"libsmd_hip{_SUFFIX}.so")
 
 
 # per-file code generation switches
@@ -52,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and not is_stale():
         return LIB_PATH
     hipcc = find_hipcc()
-    objdir = os.path.join(CSRC, "build")
+    objdir = os.path.join(CSRC, "build" + _SUFFIX)
     os.makedirs(objdir, exist_ok=True)
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
 

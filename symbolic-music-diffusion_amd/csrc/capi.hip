@@ -87,6 +87,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
+  if (std::string(key) == "mlp_hs") { e->impl.mlp_hs = value ? 1 : 0; return 0; }
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;
 }
@@ -162,6 +163,32 @@ int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* ga
                       smd_bf16* save_u, void* stream) {
   return launch_mlp_block_fwd(h_in, h_out, rows, gamma, beta, B(W1t), b1, B(W2t), b2, hidden, B(save_a2), B(save_z1), B(save_u),
                               S(stream));
+}
+int smd_mlp_block_fwd_hs(const smd_bf16* a2, const float* h_res, int rows, const smd_bf16* W1t, const float* b1,
+                         const smd_bf16* W2t, const float* b2, int hidden, float* part, void* stream) {
+  return launch_mlp_block_fwd_hs(B(a2), h_res, rows, B(W1t), b1, B(W2t), b2, hidden, part, S(stream));
+}
+int smd_mlp_block_bwd_hs(const smd_bf16* a2, const smd_bf16* dh, int rows, const smd_bf16* W1t, const smd_bf16* W2, const smd_bf16* W1,
+                         const float* b1, int hidden, smd_bf16* u, smd_bf16* dz, float* part, void* stream) {
+  return launch_mlp_block_bwd_hs(B(a2), B(dh), rows, B(W1t), B(W2), B(W1), b1, hidden, B(u), B(dz), part, S(stream));
+}
+int smd_ln128_bwd_parts(const float* x, const float* parts, int64_t part_stride, int rows, const float* gamma, const float* dres,
+                        float* dx_f32, smd_bf16* dx_bf16, float* partial, void* stream) {
+  return launch_ln128_bwd_parts(x, parts, (size_t)part_stride, rows, gamma, dres, dx_f32, B(dx_bf16), partial, S(stream));
+}
+int smd_ln128_parts(const float* parts, int64_t part_stride, int rows, const float* gamma, const float* beta, float* x_out,
+                    smd_bf16* ln_out, void* stream) {
+  return launch_ln128_parts(parts, (size_t)part_stride, rows, gamma, beta, x_out, B(ln_out), S(stream));
+}
+int smd_attn_block_fwd_ex(const float* h_in, const float* h_parts, int64_t part_stride, float* h_comb, float* h_out, int rows,
+                          const float* gamma, const float* beta, const smd_bf16* Wqkv_t, const float* b_qkv,
+                          const smd_bf16* Wo_t, const float* b_o, int num_heads, const float* gamma2, const float* beta2,
+                          smd_bf16* a2_out, smd_bf16* save_a1, smd_bf16* save_qkv, smd_bf16* save_o, void* stream) {
+  AttnBlockExtra ex;
+  ex.h_parts = h_parts; ex.part_stride = (size_t)part_stride; ex.h_comb = h_comb; ex.gamma2 = gamma2; ex.beta2 = beta2;
+  ex.a2_out = B(a2_out);
+  return launch_attn_block_fwd(h_in, h_out, rows, gamma, beta, B(Wqkv_t), b_qkv, B(Wo_t), b_o, num_heads, B(save_a1), B(save_qkv),
+                               B(save_o), S(stream), &ex);
 }
 int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta, const smd_bf16* Wqkv_t,
                        const float* b_qkv, const smd_bf16* Wo_t, const float* b_o, int num_heads, smd_bf16* save_a1,

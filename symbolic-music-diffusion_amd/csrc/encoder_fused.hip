@@ -423,6 +423,520 @@ __global__ __launch_bounds__(512) void mlp_block_fwd8_kernel(MlpArgs a) {
   }
 }
 
+// All-reduce of R independent values per lane over the 64 lanes of a wave; the R chains are interleaved step by
+// step so that the exchange latencies overlap.  Default: six xor exchanges through the LDS crossbar (ds_bpermute,
+// __shfl_xor) -- every step adds two commuting operands, so all lanes end with the bitwise identical sum.
+// SMD_ALLREDUCE_DPP (experiment builds only): the four intra-row steps as DPP operations,
+//   1 = as hipcc schedules them (dependent DPP reads at the hazard recognizer's minimum distance of two wait states),
+//   2 = every DPP step preceded by s_nop 4 inside one asm statement.
+#ifndef SMD_ALLREDUCE_DPP
+#define SMD_ALLREDUCE_DPP 0
+#endif
+template <int R>
+__device__ __forceinline__ void wave_allreduce_sum(float (&v)[R]) {
+#if SMD_ALLREDUCE_DPP == 1
+#define SMD_DPP_ADD(CTRL)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < R; ++i)                                                                    \
+    v[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), CTRL, 0xF, 0xF, true));
+  SMD_DPP_ADD(0xB1)    // quad_perm [1,0,3,2]
+  SMD_DPP_ADD(0x4E)    // quad_perm [2,3,0,1]
+  SMD_DPP_ADD(0x141)   // row_half_mirror
+  SMD_DPP_ADD(0x140)   // row_mirror
+#undef SMD_DPP_ADD
+#elif SMD_ALLREDUCE_DPP == 2
+#define SMD_DPP_ADD(CTRL)                                                                                          \
+  _Pragma("unroll") for (int i = 0; i < R; ++i)                                                                    \
+    asm volatile("s_nop 4\n\tv_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1" : "+v"(v[i]));
+  SMD_DPP_ADD("quad_perm:[1,0,3,2]")
+  SMD_DPP_ADD("quad_perm:[2,3,0,1]")
+  SMD_DPP_ADD("row_half_mirror")
+  SMD_DPP_ADD("row_mirror")
+#undef SMD_DPP_ADD
+#else
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] += __shfl_xor(v[i], o, 64);
+  }
+#endif
+#pragma unroll
+  for (int i = 0; i < R; ++i) v[i] += __shfl_xor(v[i], 16, 64);
+#pragma unroll
+  for (int i = 0; i < R; ++i) v[i] += __shfl_xor(v[i], 32, 64);
+}
+
+// =====================================================================================================
+//   mlp_hs_fwd: the MLP half-layer with the HIDDEN dimension split over workgroups ("hs").
+//
+// The one-sample-per-workgroup kernels above make every CU stream all of W1 + W2 (1 MiB) through its LDS; that stream
+// (~36 GB/s per CU whatever the schedule) is their whole run time.  Here a workgroup owns NS
+// samples x one QUARTER of the hidden units: 256 KiB of weights per CU instead of 1 MiB, every weight fragment read
+// from LDS once per NS samples, the same number of workgroups (B/NS x 4).  Per 128-unit chunk:
+//   GEMM1  z^T[hidden][token] = W1[chunk] a2^T  (+ b1, GELU)  -> u tile in LDS (row-major [token][hidden], bf16)
+//   GEMM2  out^T[n][token]   += W2t[:, chunk] u^T            (wave = 32 output features x 16 tokens: no cross-wave sum)
+// Both are 16x16x32 MFMAs with the weight slice as the A operand (rows DMA'd as they lie in the operand pack).
+// The LayerNorm is NOT in here: the attention kernel of the same layer emits a2 = ln2(h_mid) (bf16), DMA'd into LDS.
+// The four hidden quarters leave four fp32 partial tiles (quarter 0 also carries b2 + the residual); the CONSUMER of
+// the residual stream -- the next layer's attention kernel, or ln128_parts_kernel for the last layer -- adds them in
+// the fixed order (p0 + p1) + (p2 + p3).  (An in-kernel last-arriver combine was measured first: 15.6 us of publish +
+// combine on a 19 us kernel, profiles/README.md.)
+// =====================================================================================================
+constexpr int HS_NQ = 4;                       // hidden quarters
+constexpr int HS_WBUF = 65536;                 // one chunk: W1 slice [128 hidden][256 B] + W2t slice [128 n][256 B]
+constexpr int HS_TILE = 2 * HS_WBUF;           // token tiles: a2 (prologue), then u, NS x [32][256 B]
+
+struct MlpHsArgs {
+  const bf16_t* a2;         // [R][128] bf16 = ln2(h_mid)
+  const float* h_res;       // [R][128] fp32 residual (h_mid)
+  const bf16_t* W1t; const float* b1; const bf16_t* W2t; const float* b2;
+  int M;
+  float* part;              // [4][R][128] fp32 partial tiles of h_out
+  int rows;
+  int dbg;
+};
+
+template <int NS>
+__global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HS_TILE + NS * 8192];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hg = w & 3, th = w >> 2;
+  const int q = blockIdx.x & (HS_NQ - 1), grp = blockIdx.x >> 2;
+  const size_t row0 = (size_t)grp * (S_TOK * NS);
+  const int g = lane >> 4, j = lane & 15;
+  const int tok = th * 16 + j;
+  const int HQ = a.M / HS_NQ, hbase = q * HQ, nchunks = HQ / CH;
+  lds_byte_ptr L = (lds_byte_ptr)smem;
+
+  // ---- DMA (as mlp_block_fwd8): round r covers tile rows r*32 + w*4 + (lane>>4), 16 lanes per 256-B row, source
+  // chunk = LDS chunk ^ (row & 15)
+  const int rl = w * 4 + (lane >> 4);
+  const uint32_t cs = (uint32_t)(((lane & 15) ^ (rl & 15)) * 16);
+  const uint32_t w1_v = (uint32_t)rl * 256u + cs;
+  const uint32_t w2_v = (uint32_t)rl * (uint32_t)(a.M * 2) + cs;
+  const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1t), 0, a.M * E_DIM * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2t), 0, a.M * E_DIM * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.a2 + row0 * E_DIM), 0, NS * 8192, 0x00020000);
+  const uint32_t w2_round = (uint32_t)(32 * a.M * 2);
+  unsigned char* lds_w = smem + w * 1024;
+  auto stage_chunk = [&](int c, int buf) {
+    unsigned char* d1 = lds_w + buf * HS_WBUF;
+    const uint32_t h0 = (uint32_t)(hbase + c * CH);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) glds16(w1_rsrc, w1_v, h0 * 256u + (uint32_t)(r * 8192), d1 + r * 8192);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) glds16(w2_rsrc, w2_v, h0 * 2u + (uint32_t)r * w2_round, d1 + W_SLICE + r * 8192);
+  };
+  float4 bnext[2];
+  auto fetch_bias = [&](int c) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) bnext[mt] = *reinterpret_cast<const float4*>(a.b1 + hbase + c * CH + hg * 32 + mt * 16 + 4 * g);
+  };
+  fetch_bias(0);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) glds16(a2_rsrc, w1_v, (uint32_t)(s * 8192), lds_w + HS_TILE + s * 8192);      // a2 tiles
+  stage_chunk(0, 0);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the a2 tiles (and the bias) have landed; chunk 0 may fly on
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  // B fragments of a2^T per sample (lane = token th*16 + j, k-chunk 4 ks + g), kept in registers for the whole kernel
+  bf16x8_t a2f[NS][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      a2f[s][ks] = *reinterpret_cast<lds_b128_ptr>(L + HS_TILE + (s * 32 + tok) * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
+
+  f32x4_t acc[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[s][mt][e] = 0.0f;
+
+  const int arow = (hg * 32 + j) * 256;                    // A-fragment row of this lane inside a slice (m-tile 0)
+  for (int c = 0; c < ((a.dbg & 1) ? 0 : nchunks); ++c) {
+    const int buf = c & 1;
+    // The W1 slice of chunk c has landed (vmcnt(4): its W2 slice, issued right behind it, may still be in flight: it
+    // is only needed after the second barrier); every wave is done with iteration c-1, so the other weight buffer and
+    // the u tiles are free (the first pass also orders the a2 fragment reads before the u writes).
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 bcur[2] = {bnext[0], bnext[1]};
+    const bool more = c + 1 < nchunks;
+    if (more) {
+      fetch_bias(c + 1);
+      stage_chunk(c + 1, buf ^ 1);
+    }
+    lds_byte_ptr s1 = L + buf * HS_WBUF;
+    lds_byte_ptr s2 = s1 + W_SLICE;
+    {
+      // ---- GEMM1: z^T tiles [16 hidden][16 tokens] x 2 m-tiles x NS samples
+      bf16x8_t wf[2][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) wf[mt][ks] = *reinterpret_cast<lds_b128_ptr>(s1 + arow + mt * 16 * 256 + (((ks * 4 + g) ^ j) << 4));
+      f32x4_t z[NS][2];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[s][mt][e] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) z[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][ks], a2f[s][ks], z[s][mt], 0, 0, 0);
+      // + b1, GELU -> u[sample][token][hidden] (hidden of z[s][mt][e]: hg*32 + mt*16 + 4g + e)
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const float bb[4] = {bcur[mt].x, bcur[mt].y, bcur[mt].z, bcur[mt].w};
+          bf16x4_t uu;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) uu[e] = f2bf(geluf_(z[s][mt][e] + bb[e]));
+          const int hid = hg * 32 + mt * 16 + 4 * g;
+          *reinterpret_cast<bf16x4_t*>(smem + HS_TILE + (s * 32 + tok) * 256 + (((hid >> 3) ^ (tok & 15)) << 4) + (hid & 7) * 2) = uu;
+        }
+    }
+    // u tiles written; the W2 slice of this chunk has landed: behind it only the next chunk's 2 bias loads + 8 DMAs
+    if (more) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      // ---- GEMM2: out^T tiles [16 n][16 tokens] += W2t[n][chunk] u^T
+      bf16x8_t vf[2][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) vf[mt][ks] = *reinterpret_cast<lds_b128_ptr>(s2 + arow + mt * 16 * 256 + (((ks * 4 + g) ^ j) << 4));
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        bf16x8_t uf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          uf[ks] = *reinterpret_cast<lds_b128_ptr>(L + HS_TILE + (s * 32 + tok) * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[mt][ks], uf[ks], acc[s][mt], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- this quarter's partial tile: out[token][n], n = hg*32 + mt*16 + 4g + e (4 consecutive per lane); quarter 0
+  // carries the bias and the residual
+  {
+    float* dst = a.part + ((size_t)q * a.rows + row0) * E_DIM;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int n0 = hg * 32 + mt * 16 + 4 * g;
+        float4 v = make_float4(acc[s][mt][0], acc[s][mt][1], acc[s][mt][2], acc[s][mt][3]);
+        if (q == 0) {
+          const float4 r = *reinterpret_cast<const float4*>(a.h_res + (row0 + s * 32 + tok) * E_DIM + n0);
+          const float4 bb = *reinterpret_cast<const float4*>(a.b2 + n0);
+          v.x += bb.x + r.x; v.y += bb.y + r.y; v.z += bb.z + r.z; v.w += bb.w + r.w;
+        }
+        *reinterpret_cast<float4*>(dst + (size_t)(s * 32 + tok) * E_DIM + n0) = v;
+      }
+  }
+}
+
+// x = (p0 + p1) + (p2 + p3) of four partial tiles (one wave per 128-wide row), optionally written out, optionally
+// followed by LayerNorm -> bf16: the consumer of the hidden-split MLP's output where no attention kernel follows
+// (the encoder's final norm, models/ncsn.py:170) and the stand-alone / test entry.
+__global__ __launch_bounds__(256) void ln128_parts_kernel(const float* __restrict__ parts, size_t part_stride, int rows,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ x_out, bf16_t* __restrict__ ln_out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const size_t o = (size_t)row * E_DIM + lane * 2;
+  const float2 p0 = *reinterpret_cast<const float2*>(parts + o), p1 = *reinterpret_cast<const float2*>(parts + part_stride + o);
+  const float2 p2 = *reinterpret_cast<const float2*>(parts + 2 * part_stride + o), p3 = *reinterpret_cast<const float2*>(parts + 3 * part_stride + o);
+  float2 x;
+  x.x = (p0.x + p1.x) + (p2.x + p3.x);
+  x.y = (p0.y + p1.y) + (p2.y + p3.y);
+  if (x_out) *reinterpret_cast<float2*>(x_out + o) = x;
+  if (ln_out) {
+    float st[2] = {x.x + x.y, x.x * x.x + x.y * x.y};
+    wave_allreduce_sum<2>(st);
+    const float mean = st[0] * (1.0f / E_DIM);
+    const float rstd = rsqrtf(st[1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+    const float2 g2 = *reinterpret_cast<const float2*>(gamma + lane * 2), b2 = *reinterpret_cast<const float2*>(beta + lane * 2);
+    bf16x2_t t;
+    t[0] = f2bf((x.x - mean) * rstd * g2.x + b2.x);
+    t[1] = f2bf((x.y - mean) * rstd * g2.y + b2.y);
+    *reinterpret_cast<bf16x2_t*>(ln_out + o) = t;
+  }
+}
+
+// =====================================================================================================
+//   mlp_hs_bwd: backward of the MLP half-layer between ln2 and the residual add, hidden split as in mlp_hs_fwd, with
+//   the hidden activations RECOMPUTED from a2 instead of saved by the forward pass (which then saves nothing):
+//     z  = a2 W1 + b1,  u = gelu(z)            (written out: X operand of the fc2 weight gradient)
+//     du = dh W2^T,     dz = du * gelu'(z)     (written out: dY operand of the fc1 weight gradient)
+//     da2 += dz W1^T                           (four fp32 partial tiles, summed by ln128_bwd_parts_kernel)
+//   A workgroup owns 4 samples x a quarter of the hidden units and walks it in chunks of 32 units; per chunk three 8-KiB
+//   weight slices are DMA'd (ring of three buffers, two chunks in flight):
+//     S1 = W1t[chunk][128 k]   A operand of z^T[h][token]  = S1 a2^T        (forward pack of fc1, rows as they lie)
+//     S2 = W2[chunk][128 n]    A operand of du^T[h][token] = S2 dh^T        (dgrad pack of fc2)
+//     S3 = W1[128 k][chunk]    A operand of da2^T[k][token] += S3 dz^T      (dgrad pack of fc1, 64-B row pieces)
+//   Waves: ht = hidden 16-tile of the chunk (and k half of da2), th = token half, sp = sample pair.  u and dz meet the
+//   third GEMM and the global stores through two small LDS tiles ([token][32 hidden], 64-B rows, chunk-swizzled).
+// =====================================================================================================
+constexpr int HB_CH = 32;
+constexpr int HB_SL = 8192;                              // one weight slice
+constexpr int HB_WBUF = 3 * HB_SL;                       // S1 | S2 | S3
+constexpr int HB_NS = 4;                                 // samples per workgroup
+constexpr int HB_A2 = 3 * HB_WBUF;                       // a2 tiles  NS x [32][256 B]
+constexpr int HB_DH = HB_A2 + HB_NS * 8192;              // dh tiles
+constexpr int HB_U = HB_DH + HB_NS * 8192;               // u stage  [NS*32 tokens][64 B]
+constexpr int HB_DZ = HB_U + HB_NS * 2048;               // dz stage
+constexpr int HB_B1 = HB_DZ + HB_NS * 2048;              // fc1 bias of this quarter (<= 2048 floats)
+constexpr int HB_SMEM = HB_B1 + (MAX_HIDDEN / HS_NQ) * 4;
+
+struct MlpHsBwdArgs {
+  const bf16_t* a2;         // [R][128] ln2 output (saved by the attention kernel)
+  const bf16_t* dh;         // [R][128] gradient wrt the half-layer output
+  const bf16_t* W1t;        // [M][128]  fc1 forward pack
+  const bf16_t* W2;         // [M][128]  fc2 dgrad pack  (kernel (in = M, out = 128))
+  const bf16_t* W1;         // [128][M]  fc1 dgrad pack  (kernel (in = 128, out = M))
+  const float* b1;
+  int M;
+  bf16_t* u;                // [R][M]
+  bf16_t* dz;               // [R][M]
+  float* part;              // [4][R][128] partial tiles of da2
+  int rows;
+};
+
+__global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[HB_SMEM];
+  constexpr int NS = HB_NS, SPW = NS / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ht = w & 1, th = (w >> 1) & 1, sp = w >> 2;
+  const int q = blockIdx.x & (HS_NQ - 1), grp = blockIdx.x >> 2;
+  const size_t row0 = (size_t)grp * (S_TOK * NS);
+  const int g = lane >> 4, j = lane & 15;
+  const int tok = th * 16 + j;
+  const int HQ = a.M / HS_NQ, hbase = q * HQ, nchunks = HQ / HB_CH;
+  lds_byte_ptr L = (lds_byte_ptr)smem;
+
+  {
+    // ---- DMA descriptors
+    const int rl = w * 4 + (lane >> 4);                                   // row of a 32-row round of 256-B rows
+    const uint32_t v256 = (uint32_t)rl * 256u + (uint32_t)(((lane & 15) ^ (rl & 15)) * 16);
+    const int k3 = w * 16 + (lane >> 2);                                  // S3: 16 rows of 64 B per wave, 4 lanes per row
+    const uint32_t v3 = (uint32_t)k3 * (uint32_t)(a.M * 2) + (uint32_t)((((lane & 3) ^ ((k3 >> 2) & 3))) * 16);
+    const __amdgpu_buffer_rsrc_t w1t_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1t), 0, a.M * E_DIM * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2), 0, a.M * E_DIM * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1), 0, a.M * E_DIM * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.a2 + row0 * E_DIM), 0, NS * 8192, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dh_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.dh + row0 * E_DIM), 0, NS * 8192, 0x00020000);
+    // fc1 bias of this quarter: 8 KiB window of b1 by DMA as well (reads past the end of b1 return 0: bounded descriptor)
+    const __amdgpu_buffer_rsrc_t b1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.b1), 0, a.M * 4, 0x00020000);
+    unsigned char* lds_w = smem + w * 1024;
+    glds16(b1_rsrc, (uint32_t)(lane * 16), (uint32_t)(hbase * 4 + w * 1024), lds_w + HB_B1);
+    auto stage_chunk = [&](int c, int buf) {
+      unsigned char* d = lds_w + buf * HB_WBUF;
+      const uint32_t h0 = (uint32_t)(hbase + c * HB_CH);
+      glds16(w1t_rsrc, v256, h0 * 256u, d);
+      glds16(w2_rsrc, v256, h0 * 256u, d + HB_SL);
+      glds16(w1_rsrc, v3, h0 * 2u, d + 2 * HB_SL);
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      glds16(a2_rsrc, v256, (uint32_t)(s * 8192), lds_w + HB_A2 + s * 8192);
+      glds16(dh_rsrc, v256, (uint32_t)(s * 8192), lds_w + HB_DH + s * 8192);
+    }
+    stage_chunk(0, 0);
+    if (nchunks > 1) stage_chunk(1, 1);
+
+    f32x4_t acc[SPW][4];
+#pragma unroll
+    for (int sl = 0; sl < SPW; ++sl)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[sl][mt][e] = 0.0f;
+
+    const int arow = (ht * 16 + j) * 256;                               // A row of S1 / S2
+    const int tswz = (tok >> 2) & 3;
+    const int srow = tid >> 2, spc = tid & 3;                           // store mapping: (token row of the group, 16-B piece)
+    for (int c = 0; c < nchunks; ++c) {
+      const int buf = c % 3;
+      // chunk c has landed; what may still be in flight behind it: chunk c+1 (3 DMAs) and the previous iteration's two
+      // 16-B stores of this thread (vmcnt counts stores, in issue order)
+      if (c + 1 < nchunks) {
+        if (c >= 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      } else {
+        if (c >= 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < nchunks) stage_chunk(c + 2, (c + 2) % 3);            // its buffer was read in iteration c-1: free
+      lds_byte_ptr s1 = L + buf * HB_WBUF, s2 = s1 + HB_SL, s3 = s1 + 2 * HB_SL;
+      {
+        bf16x8_t wf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          wf[ks] = *reinterpret_cast<lds_b128_ptr>(s1 + arow + (((ks * 4 + g) ^ j) << 4));
+          vf[ks] = *reinterpret_cast<lds_b128_ptr>(s2 + arow + (((ks * 4 + g) ^ j) << 4));
+        }
+        const f32x4_t bb4 = *reinterpret_cast<const __attribute__((address_space(3))) f32x4_t*>(L + HB_B1 + (c * HB_CH + ht * 16 + 4 * g) * 4);
+        const float bb[4] = {bb4[0], bb4[1], bb4[2], bb4[3]};
+#pragma unroll
+        for (int sl = 0; sl < SPW; ++sl) {
+          const int s = sp * SPW + sl;
+          f32x4_t z, du;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = du[e] = 0.0f;
+          lds_byte_ptr ta = L + HB_A2 + (s * 32 + tok) * 256, td = L + HB_DH + (s * 32 + tok) * 256;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int co = ((ks * 4 + g) ^ (tok & 15)) << 4;
+            const bf16x8_t fa = *reinterpret_cast<lds_b128_ptr>(ta + co);
+            const bf16x8_t fd = *reinterpret_cast<lds_b128_ptr>(td + co);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], fa, z, 0, 0, 0);
+            du = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], fd, du, 0, 0, 0);
+          }
+          // hidden of element e: c*32 + ht*16 + 4g + e, token = tok
+          bf16x4_t u4, d4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float zz = z[e] + bb[e];
+            u4[e] = f2bf(geluf_(zz));
+            d4[e] = f2bf(du[e] * gelu_gradf_(zz));
+          }
+          const int piece = ht * 2 + (g >> 1);
+          const int off = (s * 32 + tok) * 64 + ((piece ^ tswz) << 4) + (g & 1) * 8;
+          *reinterpret_cast<bf16x4_t*>(smem + HB_U + off) = u4;
+          *reinterpret_cast<bf16x4_t*>(smem + HB_DZ + off) = d4;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        // ---- da2^T[k][token] += S3[k][chunk] dz^T : wave = k half ht (4 m-tiles) x token half x sample pair
+        bf16x8_t kf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int kr = (ht * 4 + mt) * 16 + j;
+          kf[mt] = *reinterpret_cast<lds_b128_ptr>(s3 + kr * 64 + ((g ^ ((kr >> 2) & 3)) << 4));
+        }
+#pragma unroll
+        for (int sl = 0; sl < SPW; ++sl) {
+          const int s = sp * SPW + sl;
+          const bf16x8_t fz = *reinterpret_cast<lds_b128_ptr>(L + HB_DZ + (s * 32 + tok) * 64 + ((g ^ tswz) << 4));
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) acc[sl][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[mt], fz, acc[sl][mt], 0, 0, 0);
+        }
+        // u / dz of this chunk -> global, one 16-B piece of a 64-B row segment per thread and tensor
+        const int po = srow * 64 + ((spc ^ ((srow >> 2) & 3)) << 4);
+        const bf16x8_t vu = *reinterpret_cast<lds_b128_ptr>(L + HB_U + po);
+        const bf16x8_t vz = *reinterpret_cast<lds_b128_ptr>(L + HB_DZ + po);
+        const size_t go = (row0 + srow) * (size_t)a.M + hbase + c * HB_CH + spc * 8;
+        *reinterpret_cast<bf16x8_t*>(a.u + go) = vu;
+        *reinterpret_cast<bf16x8_t*>(a.dz + go) = vz;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- partial tile of da2: k = (ht*4 + mt)*16 + 4g + e (4 consecutive per lane), token = tok
+    float* dst = a.part + ((size_t)q * a.rows + row0) * E_DIM;
+#pragma unroll
+    for (int sl = 0; sl < SPW; ++sl)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        *reinterpret_cast<float4*>(dst + (size_t)((sp * SPW + sl) * 32 + tok) * E_DIM + (ht * 4 + mt) * 16 + 4 * g) =
+            make_float4(acc[sl][mt][0], acc[sl][mt][1], acc[sl][mt][2], acc[sl][mt][3]);
+  }
+}
+
+// LayerNorm backward on a gradient given as four partial tiles: dout = (p0 + p1) + (p2 + p3) (fp32), x fp32,
+//   dx = LN-backward(dout) + dres  -> fp32 (may alias dres) and bf16;  dgamma / dbeta partial sums per 32-row group.
+// One wave per row (two columns per lane), 8 rows per wave in flight, 32 rows per workgroup.
+// DRES / F32 / B16: which optional operands exist -- compile-time, so that every load and store of the kernel is
+// unconditional straight-line code (kernels with runtime-conditional loads in unrolled loops were the
+// ones that lost bitwise repeatability next to the side stream).
+template <bool DRES, bool F32, bool B16>
+__global__ __launch_bounds__(256) void ln128_bwd_parts_kernel(const float* __restrict__ x, const float* __restrict__ parts,
+                                                              size_t part_stride, const float* __restrict__ gamma,
+                                                              const float* dres, float* dx_f32, bf16_t* __restrict__ dx_bf16,
+                                                              float* __restrict__ partial) {
+  __shared__ float red[4][2][E_DIM];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const size_t r0 = (size_t)blockIdx.x * 32 + w * 8;
+  const float2 g2 = *reinterpret_cast<const float2*>(gamma + lane * 2);
+  float2 xv[8], dv[8], rv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const size_t o = (r0 + i) * E_DIM + lane * 2;
+    xv[i] = *reinterpret_cast<const float2*>(x + o);
+    const float2 p0 = *reinterpret_cast<const float2*>(parts + o), p1 = *reinterpret_cast<const float2*>(parts + part_stride + o);
+    const float2 p2 = *reinterpret_cast<const float2*>(parts + 2 * part_stride + o), p3 = *reinterpret_cast<const float2*>(parts + 3 * part_stride + o);
+    dv[i].x = (p0.x + p1.x) + (p2.x + p3.x);
+    dv[i].y = (p0.y + p1.y) + (p2.y + p3.y);
+    if constexpr (DRES) rv[i] = *reinterpret_cast<const float2*>(dres + o);
+    else rv[i] = make_float2(0.f, 0.f);
+  }
+  float st[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { st[2 * i] = xv[i].x + xv[i].y; st[2 * i + 1] = xv[i].x * xv[i].x + xv[i].y * xv[i].y; }
+  wave_allreduce_sum<16>(st);
+  float Px = 0.f, Py = 0.f, Qx = 0.f, Qy = 0.f;
+  float tt[16], rs[8];
+  float2 xh[8], dxh[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float mean = st[2 * i] * (1.0f / E_DIM);
+    rs[i] = rsqrtf(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+    xh[i].x = (xv[i].x - mean) * rs[i];
+    xh[i].y = (xv[i].y - mean) * rs[i];
+    Qx += dv[i].x; Qy += dv[i].y;
+    Px += dv[i].x * xh[i].x; Py += dv[i].y * xh[i].y;
+    dxh[i].x = dv[i].x * g2.x; dxh[i].y = dv[i].y * g2.y;
+    tt[2 * i] = dxh[i].x + dxh[i].y;
+    tt[2 * i + 1] = dxh[i].x * xh[i].x + dxh[i].y * xh[i].y;
+  }
+  wave_allreduce_sum<16>(tt);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float t1 = tt[2 * i] * (1.0f / E_DIM), t2 = tt[2 * i + 1] * (1.0f / E_DIM);
+    float2 o;
+    o.x = rs[i] * (dxh[i].x - t1 - xh[i].x * t2) + rv[i].x;
+    o.y = rs[i] * (dxh[i].y - t1 - xh[i].y * t2) + rv[i].y;
+    const size_t off = (r0 + i) * E_DIM + lane * 2;
+    if constexpr (F32) *reinterpret_cast<float2*>(dx_f32 + off) = o;
+    if constexpr (B16) {
+      bf16x2_t t;
+      t[0] = f2bf(o.x); t[1] = f2bf(o.y);
+      *reinterpret_cast<bf16x2_t*>(dx_bf16 + off) = t;
+    }
+  }
+  red[w][0][lane * 2] = Px; red[w][0][lane * 2 + 1] = Py;
+  red[w][1][lane * 2] = Qx; red[w][1][lane * 2 + 1] = Qy;
+  __syncthreads();
+  {
+    const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+    partial[((size_t)blockIdx.x * 2 + which) * E_DIM + c] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+  }
+}
+
 // =====================================================================================================
 //   attn_block_fwd:  h_mid = h_in + out_proj( softmax(q k^T / sqrt(d)) v ),  q,k,v = Dense(LN(h_in))     (:159-162)
 //
@@ -441,7 +955,9 @@ constexpr int AT_Q = AT_A1 + 8192;                        // q (scaled) [32][256
 constexpr int AT_K = AT_Q + 8192;                         // k [32][256 B]
 constexpr int VT_LD = 72;                                 // v^T row: 32 keys bf16 + 8 B pad (conflict-free b64 gathers)
 constexpr int AT_VT = AT_K + 8192;                        // v^T [128][72 B]
-constexpr int AT_SMEM = AT_VT + 128 * VT_LD;
+constexpr int AT_XS = AT_VT + 128 * VT_LD;                // combined input rows [32][128] fp32 (partial-sum input only)
+constexpr int AT_ST = AT_XS + S_TOK * E_DIM * 4;          // LN2 row statistics of the output: [4 waves][32 tokens][2]
+constexpr int AT_SMEM = AT_ST + 4 * S_TOK * 2 * 4;
 
 struct AttnArgs {
   const float* h_in; float* h_out;
@@ -453,6 +969,11 @@ struct AttnArgs {
   bf16_t* save_a1;          // [R][128] or null
   bf16_t* save_qkv;         // [R][384] or null (q unscaled, as the unfused path stores it)
   bf16_t* save_o;           // [R][128] or null
+  // the input as a sum of partial tiles (hidden-split MLP of the layer below): x = ((p0 + p1) + (p2 + p3)), parts
+  // h_parts + k * part_stride; h_in is then unused.  h_comb (nullable): x written out (training keeps it)
+  const float* h_parts; size_t part_stride; float* h_comb;
+  // LayerNorm of the OUTPUT rows (the ln2 of the same encoder layer) -> a2_out bf16 [R][128], or null
+  const float* gamma2; const float* beta2; bf16_t* a2_out;
 };
 
 template <int DH>
@@ -478,16 +999,33 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     const float2 g2 = *reinterpret_cast<const float2*>(a.gamma + lane * 2);
     const float2 b2v = *reinterpret_cast<const float2*>(a.beta + lane * 2);
     float2 x[8];
+    if (a.h_parts) {
+      float2 pp[4][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 8 + i) * E_DIM + lane * 2);
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          pp[k][i] = *reinterpret_cast<const float2*>(a.h_parts + k * a.part_stride + (row0 + w * 8 + i) * E_DIM + lane * 2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        x[i].x = (pp[0][i].x + pp[1][i].x) + (pp[2][i].x + pp[3][i].x);
+        x[i].y = (pp[0][i].y + pp[1][i].y) + (pp[2][i].y + pp[3][i].y);
+        *reinterpret_cast<float2*>(smem + AT_XS + ((w * 8 + i) * E_DIM + lane * 2) * 4) = x[i];
+        if (a.h_comb) *reinterpret_cast<float2*>(a.h_comb + (row0 + w * 8 + i) * E_DIM + lane * 2) = x[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 8 + i) * E_DIM + lane * 2);
+    }
+    float st[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st[2 * i] = x[i].x + x[i].y; st[2 * i + 1] = x[i].x * x[i].x + x[i].y * x[i].y; }
+    wave_allreduce_sum<16>(st);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = w * 8 + i;
-      float s = x[i].x + x[i].y, s2 = x[i].x * x[i].x + x[i].y * x[i].y;
-      s = wave_sum(s);
-      s2 = wave_sum(s2);
-      const float mean = s * (1.0f / E_DIM);
-      const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      const float mean = st[2 * i] * (1.0f / E_DIM);
+      const float rstd = rsqrtf(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
       bf16x2_t o;
       o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
       o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
@@ -639,7 +1177,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
   float4 res[4], bo[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    res[g] = *reinterpret_cast<const float4*>(a.h_in + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g);
+    if (a.h_parts) res[g] = *reinterpret_cast<const float4*>(smem + AT_XS + (l31 * E_DIM + w * 32 + 4 * kh + 8 * g) * 4);
+    else res[g] = *reinterpret_cast<const float4*>(a.h_in + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g);
     bo[g] = *reinterpret_cast<const float4*>(a.b_o + w * 32 + 4 * kh + 8 * g);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // Wo landed (and the loads above)
@@ -659,6 +1198,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
       co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fo, co, 0, 0, 0);
     }
   }
+  float4 ov[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     float4 o;
@@ -667,6 +1207,38 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     o.z = co[4 * g + 2] + bo[g].z + res[g].z;
     o.w = co[4 * g + 3] + bo[g].w + res[g].w;
     *reinterpret_cast<float4*>(a.h_out + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g) = o;
+    ov[g] = o;
+  }
+  if (a.a2_out) {
+    // ---- ln2 of the output rows: this lane holds 16 of token l31's 128 features; the other 112 sit in the other lane
+    // half (xor 32) and in the other three waves (through LDS), summed in a fixed order
+    float ps = 0.f, ps2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ps += (ov[g].x + ov[g].y) + (ov[g].z + ov[g].w);
+      ps2 += (ov[g].x * ov[g].x + ov[g].y * ov[g].y) + (ov[g].z * ov[g].z + ov[g].w * ov[g].w);
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    ps2 += __shfl_xor(ps2, 32, 64);
+    float* stt = reinterpret_cast<float*>(smem + AT_ST);
+    if (kh == 0) { stt[(w * S_TOK + l31) * 2] = ps; stt[(w * S_TOK + l31) * 2 + 1] = ps2; }
+    __syncthreads();
+    float s = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { s += stt[(ww * S_TOK + l31) * 2]; s2 += stt[(ww * S_TOK + l31) * 2 + 1]; }
+    const float mean = s * (1.0f / E_DIM);
+    const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int f = w * 32 + 4 * kh + 8 * g;
+      const float4 gg = *reinterpret_cast<const float4*>(a.gamma2 + f), bb = *reinterpret_cast<const float4*>(a.beta2 + f);
+      bf16x4_t t;
+      t[0] = f2bf((ov[g].x - mean) * rstd * gg.x + bb.x);
+      t[1] = f2bf((ov[g].y - mean) * rstd * gg.y + bb.y);
+      t[2] = f2bf((ov[g].z - mean) * rstd * gg.z + bb.z);
+      t[3] = f2bf((ov[g].w - mean) * rstd * gg.w + bb.w);
+      *reinterpret_cast<bf16x4_t*>(a.a2_out + (row0 + l31) * E_DIM + f) = t;
+    }
   }
 }
 
@@ -966,14 +1538,82 @@ int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float*
   return 0;
 }
 
+int mlp_hs_samples_per_group(int rows, int M) {
+  if (rows <= 0 || rows % S_TOK || M % (HS_NQ * CH) || M > MAX_HIDDEN) return 0;
+  const int B = rows / S_TOK;
+  return B % 4 == 0 ? 4 : (B % 2 == 0 ? 2 : 1);
+}
+
+int launch_mlp_block_fwd_hs(const bf16_t* a2, const float* h_res, int rows, const bf16_t* W1t, const float* b1,
+                            const bf16_t* W2t, const float* b2, int M, float* part, hipStream_t st) {
+  SMD_ARG_CHECK(a2 && h_res && W1t && b1 && W2t && b2 && part, "mlp_block_fwd_hs: null pointer");
+  const int ns = mlp_hs_samples_per_group(rows, M);
+  SMD_ARG_CHECK(ns > 0, "mlp_block_fwd_hs: rows=%d must be a multiple of 32 and the hidden width %d a multiple of 512 (<= 8192)", rows, M);
+  MlpHsArgs a;
+  a.a2 = a2; a.h_res = h_res; a.W1t = W1t; a.b1 = b1; a.W2t = W2t; a.b2 = b2; a.M = M; a.part = part; a.rows = rows;
+  a.dbg = smd_tuning_get("mlp_hs_dbg");
+  const dim3 grid((rows / (S_TOK * ns)) * HS_NQ), block(512);
+  if (ns == 4) hipLaunchKernelGGL(mlp_hs_fwd_kernel<4>, grid, block, 0, st, a);
+  else if (ns == 2) hipLaunchKernelGGL(mlp_hs_fwd_kernel<2>, grid, block, 0, st, a);
+  else hipLaunchKernelGGL(mlp_hs_fwd_kernel<1>, grid, block, 0, st, a);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_mlp_block_bwd_hs(const bf16_t* a2, const bf16_t* dh, int rows, const bf16_t* W1t, const bf16_t* W2, const bf16_t* W1,
+                            const float* b1, int M, bf16_t* u, bf16_t* dz, float* part, hipStream_t st) {
+  SMD_ARG_CHECK(a2 && dh && W1t && W2 && W1 && b1 && u && dz && part, "mlp_block_bwd_hs: null pointer");
+  SMD_ARG_CHECK(rows > 0 && rows % (S_TOK * HB_NS) == 0 && M % (HS_NQ * CH) == 0 && M <= MAX_HIDDEN,
+                "mlp_block_bwd_hs: rows=%d must be a multiple of 128 and the hidden width %d a multiple of 512 (<= 8192)", rows, M);
+  MlpHsBwdArgs a;
+  a.a2 = a2; a.dh = dh; a.W1t = W1t; a.W2 = W2; a.W1 = W1; a.b1 = b1; a.M = M; a.u = u; a.dz = dz; a.part = part; a.rows = rows;
+  hipLaunchKernelGGL(mlp_hs_bwd_kernel, dim3((rows / (S_TOK * HB_NS)) * HS_NQ), dim3(512), 0, st, a);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ln128_bwd_parts(const float* x, const float* parts, size_t part_stride, int rows, const float* gamma, const float* dres,
+                           float* dx_f32, bf16_t* dx_bf16, float* partial, hipStream_t st) {
+  SMD_ARG_CHECK(x && parts && gamma && partial && (dx_f32 || dx_bf16), "ln128_bwd_parts: null pointer");
+  SMD_ARG_CHECK(rows > 0 && rows % 32 == 0, "ln128_bwd_parts: rows=%d must be a multiple of 32", rows);
+  const dim3 grid(rows / 32), block(256);
+  // "ln_excl" (experiment): pad the launch with dynamic LDS so that the workgroup cannot share a CU
+  // with a 64-KiB workgroup of the side stream's weight-gradient GEMMs
+  const int pad = smd_tuning_get("ln_excl") > 0 ? smd_tuning_get("ln_excl") * 1024 : 0;
+#define SMD_LNB(D_, F_, B_)                                                                                           \
+  do {                                                                                                                \
+    if (pad > 65536) (void)hipFuncSetAttribute((const void*)ln128_bwd_parts_kernel<D_, F_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, pad); \
+    hipLaunchKernelGGL((ln128_bwd_parts_kernel<D_, F_, B_>), grid, block, pad, st, x, parts, part_stride, gamma, dres, dx_f32, dx_bf16, partial); \
+  } while (0)
+  if (dres) {
+    if (dx_f32 && dx_bf16) SMD_LNB(true, true, true); else if (dx_f32) SMD_LNB(true, true, false); else SMD_LNB(true, false, true);
+  } else {
+    if (dx_f32 && dx_bf16) SMD_LNB(false, true, true); else if (dx_f32) SMD_LNB(false, true, false); else SMD_LNB(false, false, true);
+  }
+#undef SMD_LNB
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ln128_parts(const float* parts, size_t part_stride, int rows, const float* gamma, const float* beta, float* x_out,
+                       bf16_t* ln_out, hipStream_t st) {
+  SMD_ARG_CHECK(parts && rows > 0 && (x_out || ln_out) && (!ln_out || (gamma && beta)), "ln128_parts: bad arguments");
+  hipLaunchKernelGGL(ln128_parts_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, parts, part_stride, rows, gamma, beta, x_out, ln_out);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
                           const bf16_t* Wqkv_t, const float* b_qkv, const bf16_t* Wo_t, const float* b_o, int num_heads,
-                          bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st) {
-  SMD_ARG_CHECK(h_in && h_out && gamma && beta && Wqkv_t && b_qkv && Wo_t && b_o, "attn_block_fwd: null pointer");
+                          bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st, const AttnBlockExtra* ex) {
+  SMD_ARG_CHECK((h_in || (ex && ex->h_parts)) && h_out && gamma && beta && Wqkv_t && b_qkv && Wo_t && b_o, "attn_block_fwd: null pointer");
   SMD_ARG_CHECK(rows > 0 && rows % S_TOK == 0, "attn_block_fwd: rows=%d must be a multiple of 32", rows);
+  SMD_ARG_CHECK(!ex || !ex->a2_out || (ex->gamma2 && ex->beta2), "attn_block_fwd: a2_out needs the ln2 parameters");
   AttnArgs a;
   a.h_in = h_in; a.h_out = h_out; a.gamma = gamma; a.beta = beta; a.Wqkv_t = Wqkv_t; a.b_qkv = b_qkv; a.Wo_t = Wo_t; a.b_o = b_o;
   a.save_a1 = save_a1; a.save_qkv = save_qkv; a.save_o = save_o;
+  a.h_parts = ex ? ex->h_parts : nullptr; a.part_stride = ex ? ex->part_stride : 0; a.h_comb = ex ? ex->h_comb : nullptr;
+  a.gamma2 = ex ? ex->gamma2 : nullptr; a.beta2 = ex ? ex->beta2 : nullptr; a.a2_out = ex ? ex->a2_out : nullptr;
   const dim3 grid(rows / S_TOK), block(256);
   switch (num_heads) {
     case 4: hipLaunchKernelGGL(attn_block_fwd_kernel<32>, grid, block, 0, st, a); break;

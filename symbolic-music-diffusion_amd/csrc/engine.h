@@ -118,6 +118,7 @@ class SmdEngine {
   int resgrad_bf16 = 1;   // ResBlock residual-gradient chain kept in bf16 (the GEMM operand copy) instead of fp32 + bf16
   int fused_encoder = 1;                                      // encoder_fused.hip half-layer kernels (0: separate launches)
   int side_wgrad = 0;
+  int mlp_hs = 1;              // hidden-split fused MLP half-layers (forward; backward with recompute); 0: the older paths
 
  private:
   int nblocks() const { return d_.arch == 0 ? d_.num_mlp_layers : d_.num_layers; }
@@ -167,6 +168,7 @@ class SmdEngine {
   std::vector<hipEvent_t> events_;             // recycled per loss_backward
   size_t next_event_ = 0;
   bool side_pending_ = false;
+  bool hs_train_ = false;                      // the forward pass of this step used the hidden-split MLP dataflow
   hipEvent_t take_event();
 
   struct Work {
@@ -214,6 +216,7 @@ class SmdEngine {
     float* norm_partial = nullptr;        // [1024]
     bf16_t* zero_page = nullptr;          // [128]
     unsigned* step_arrive = nullptr;      // [64] arrival counter of the fused reverse step
+    float* mlp_part = nullptr;            // [4][R][E] partial tiles of the hidden-split MLP kernels
     bf16_t* tn_scratch = nullptr;         // fallback wgrad transposes
     size_t tn_scratch_elems = 0;
   } W;

@@ -238,6 +238,9 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
   Work t;
   t.zero_page = c.take<bf16_t>(128);
   t.step_arrive = c.take<unsigned>(64);               // arrival counter of the fused reverse step (zeroed with the workspace)
+  if (d_.arch == 0) {
+    t.mlp_part = c.take<float>((size_t)4 * R * E);
+  }
   t.x_bf16 = c.take<bf16_t>(R * Cp_);
   t.pe = c.take<float>((size_t)S * E);
   t.pred = c.take<float>(R * C);
@@ -406,6 +409,13 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       ep.out_f32 = W.h[0]; ep.ld_out = E;
       RC(dense_fwd(in_proj_, W.x_bf16, Cp_, R, ep, st));
     }
+    // Hidden-split MLP dataflow (inference): the attention kernel of layer l sums the four partial tiles the MLP of
+    // layer l-1 left, and emits a2 = ln2(h_mid) for its own MLP; the final norm sums the last layer's tiles.
+    // training needs groups of 4 samples (the backward kernel's shape) and the fused attention backward
+    const bool hs = mlp_hs && fused_encoder && S == 32 && E == 128 && mlp_hs_samples_per_group(R, M) > 0 &&
+                    (!tr || (R % 128 == 0 && fused_encoder == 1 && tr_path));
+    if (tr) hs_train_ = hs;
+    bool parts_pending = false;
     for (int l = 0; l < d_.num_layers; ++l) {   // models/ncsn.py:158-168
       const int i = tr ? l : 0;
       float* h_in = W.h[i];
@@ -414,11 +424,17 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       const EncLayerP& p = enc_[l];
       LnArgs ln;
       ln.rows = R; ln.D = E;
+      const bool layer_hs = hs && p.qkv.Kp == E && p.out.Kp == E && p.fc1.Kp == E && p.fc2.Kp == M;
       if (fused_encoder && S == 32 && E == 128 && p.qkv.Kp == E && p.out.Kp == E) {
         // LN1 + QKV + softmax(q k^T) v + out_proj + residual in one launch (saved activations are small: also training)
-        RC(launch_attn_block_fwd(h_in, h_mid, R, P(p.ln1.g_off), P(p.ln1.b_off), wpack_ + p.qkv.Wt_off, P(p.qkv.b_off),
-                                 wpack_ + p.out.Wt_off, P(p.out.b_off), d_.num_heads, tr ? W.a1[i] : nullptr,
-                                 tr ? W.qkv[i] : nullptr, tr ? W.o[i] : nullptr, st));
+        AttnBlockExtra ex;
+        if (parts_pending) { ex.h_parts = W.mlp_part; ex.part_stride = (size_t)R * E; if (tr) ex.h_comb = h_in; }
+        if (layer_hs) { ex.gamma2 = P(p.ln2.g_off); ex.beta2 = P(p.ln2.b_off); ex.a2_out = W.a2[i]; }
+        // the in-place inference stream: with a partial-sum input the kernel never reads h_in, h_mid may be h[0]
+        RC(launch_attn_block_fwd(parts_pending ? nullptr : h_in, h_mid, R, P(p.ln1.g_off), P(p.ln1.b_off), wpack_ + p.qkv.Wt_off,
+                                 P(p.qkv.b_off), wpack_ + p.out.Wt_off, P(p.out.b_off), d_.num_heads, tr ? W.a1[i] : nullptr,
+                                 tr ? W.qkv[i] : nullptr, tr ? W.o[i] : nullptr, st, &ex));
+        parts_pending = false;
       } else {
         ln.x = h_in; ln.gamma = P(p.ln1.g_off); ln.beta = P(p.ln1.b_off); ln.out = W.a1[i];
         RC(launch_layernorm_fwd(ln, st));
@@ -427,7 +443,11 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
         { GemmEpilogue ep; ep.res_f32 = h_in; ep.ld_res = E; ep.out_f32 = h_mid; ep.ld_out = E;
           RC(dense_fwd(p.out, W.o[i], E, R, ep, st)); }
       }
-      if (fused_encoder && (!tr || fused_encoder == 2) && S == 32 && E == 128 && M % 128 == 0 && p.fc1.Kp == E && p.fc2.Kp == M) {
+      if (layer_hs) {
+        RC(launch_mlp_block_fwd_hs(W.a2[i], h_mid, R, wpack_ + p.fc1.Wt_off, P(p.fc1.b_off), wpack_ + p.fc2.Wt_off,
+                                   P(p.fc2.b_off), M, W.mlp_part, st));
+        parts_pending = true;
+      } else if (fused_encoder && (!tr || fused_encoder == 2) && S == 32 && E == 128 && M % 128 == 0 && p.fc1.Kp == E && p.fc2.Kp == M) {
         // LN2 + fc1 + GELU + fc2 + residual in one launch; the 2048-wide hidden stays in registers.  Inference
         // only by default: with the three saved activations the fused kernel is store-bound (8-byte stores
         // from the MFMA C layout) and no faster than the separate GEMMs (option fused_encoder = 2 forces it).
@@ -445,9 +465,13 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       }
     }
     {  // models/ncsn.py:170-171
-      LnArgs ln;
-      ln.x = W.h_last; ln.rows = R; ln.D = E; ln.gamma = P(ln_f_.g_off); ln.beta = P(ln_f_.b_off); ln.out = W.af;
-      RC(launch_layernorm_fwd(ln, st));
+      if (parts_pending) {
+        RC(launch_ln128_parts(W.mlp_part, (size_t)R * E, R, P(ln_f_.g_off), P(ln_f_.b_off), tr ? W.h_last : nullptr, W.af, st));
+      } else {
+        LnArgs ln;
+        ln.x = W.h_last; ln.rows = R; ln.D = E; ln.gamma = P(ln_f_.g_off); ln.beta = P(ln_f_.b_off); ln.out = W.af;
+        RC(launch_layernorm_fwd(ln, st));
+      }
       GemmEpilogue ep; ep.out_f32 = y0; ep.ld_out = M;
       RC(dense_fwd(up_, W.af, E, R, ep, st));
     }
@@ -620,10 +644,25 @@ int SmdEngine::backward_stem(hipStream_t st) {
     bf16_t* dh_in = W.dhb[2 * l + 2];
     bf16_t* dh_mid = W.dhb[2 * l + 1];
     bf16_t* dh_out = W.dhb[2 * l];
-    // mlp.fc2: h_out = u W2 + b + h_mid ; dz1 = (dh W2^T) * gelu'(z1)
-    RC(dense_bwd(p.fc2, W.u[l], M, dh_in, E, R, W.dz1[l], M, W.z1[l], M, SMD_AUX_GELU_GRAD, st, true));
-    RC(dense_bwd(p.fc1, W.a2[l], E, W.dz1[l], M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
-    {
+    if (hs_train_) {
+      // fused backward with the hidden activations recomputed from a2: writes u and dz1 (wgrad operands) and four
+      // partial tiles of da2; the ln2 backward sums them (launch-boundary reduce)
+      RC(launch_mlp_block_bwd_hs(W.a2[l], dh_in, R, wpack_ + p.fc1.Wt_off, wpack_ + p.fc2.W_off, wpack_ + p.fc1.W_off, P(p.fc1.b_off),
+                                 M, W.u[l], W.dz1[l], W.mlp_part, st));
+      RC(wgrad(p.fc2, W.u[l], M, dh_in, E, R, true, st));
+      RC(wgrad(p.fc1, W.a2[l], E, W.dz1[l], M, R, true, st));
+      const size_t need = (size_t)(R / 32) * 2 * E;
+      SMD_ARG_CHECK(ln_slot_off_ + need <= W.ln_partial_elems, "backward_stem: LayerNorm partial workspace exhausted");
+      float* partial = W.ln_partial + ln_slot_off_;
+      ln_slot_off_ += need;
+      RC(launch_ln128_bwd_parts(W.h_mid[l], W.mlp_part, (size_t)R * E, R, P(p.ln2.g_off), W.dh, W.dh, dh_mid, partial, st));
+      LnReduceEntry en;
+      en.partial = partial; en.ngroups = R / 32; en.D = E; en.dgamma = G(p.ln2.g_off); en.dbeta = G(p.ln2.b_off); en.block_start = 0;
+      ln_pending_.push_back(en);
+    } else {
+      // mlp.fc2: h_out = u W2 + b + h_mid ; dz1 = (dh W2^T) * gelu'(z1)
+      RC(dense_bwd(p.fc2, W.u[l], M, dh_in, E, R, W.dz1[l], M, W.z1[l], M, SMD_AUX_GELU_GRAD, st, true));
+      RC(dense_bwd(p.fc1, W.a2[l], E, W.dz1[l], M, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
       LnBwdArgs b;
       b.f = ln_args(W.h_mid[l], nullptr, R, p.ln2, params_);
       b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_mid;

@@ -410,6 +410,12 @@ int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out
 }
 
 // room for 4 split partials of a 2048x2048 weight (gemm_tn256) + bias partial rows
+int smd_tn_pad_bytes(int static_lds_bytes) {
+  if (!smd_tuning_get("tn_exclusive_cu")) return 0;
+  const int pad = 160 * 1024 - static_lds_bytes;
+  return pad > 0 ? pad : 0;
+}
+
 size_t gemm_tn_slab_elems() { return (size_t)4 * 2048 * 2048 + (size_t)1024 * 1024; }
 
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
@@ -446,7 +452,8 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
     a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t.slab; a.slab_stride = stride;
     a.tiles_n = tiles_n; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t.zero_page;
-    if (per >= 6 && smd_tuning_get("gemm_tn_deep")) hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    if (smd_tuning_get("tn_exclusive_cu") || (per >= 6 && smd_tuning_get("gemm_tn_deep")))
+      hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga);
     else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
@@ -524,7 +531,9 @@ int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st) {
       blocks += (int)(((size_t)t.Kd * t.N + (t.bias_out ? t.N : 0) + 255) / 256);
       slab_off += (size_t)nsplit * stride;
     }
-    hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    // tn_exclusive_cu (default): the 4-buffer instantiation padded to the CU's whole LDS, see smd_tn_pad_bytes()
+    if (smd_tuning_get("tn_exclusive_cu")) hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga);
+    else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ra);

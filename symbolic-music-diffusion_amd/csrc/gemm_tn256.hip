@@ -21,6 +21,7 @@
 //     carries 1/tiles_k of the column-sum work; the partial rows are summed by the same reduce kernel.
 #include "smd_kernels.h"
 
+// dynamic-LDS pad that makes a weight-gradient workgroup fill a CU's LDS (smd_kernels.h)
 namespace {
 
 constexpr int TM = 256, TN = 256, TKM = 64;
@@ -391,7 +392,7 @@ int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipSt
   ga.ngroups = 1;
   fill_tn256(ga.p[0], t, nsplit, ktiles_per_split, t.slab);
   ga.nwg_total = ga.p[0].nwg;
-  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), 0, st, ga);
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), smd_tn_pad_bytes(SMEM_BYTES), st, ga);
   SMD_LAUNCH_CHECK();
   return reduce_tn256(t, ga.p[0], nsplit, st);
 }
@@ -418,7 +419,7 @@ int launch_gemm_tn256_pair(const TnLaunch& t0, const TnLaunch& t1, hipStream_t s
   fill_tn256(ga.p[0], t0, nsplit, per, t0.slab);
   fill_tn256(ga.p[1], t1, nsplit, per, t0.slab + ((need0 + 3) / 4 * 4));
   ga.nwg_total = ga.p[0].nwg + ga.p[1].nwg;
-  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), 0, st, ga);
+  hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), smd_tn_pad_bytes(SMEM_BYTES), st, ga);
   SMD_LAUNCH_CHECK();
   int rc = reduce_tn256(t0, ga.p[0], nsplit, st);
   if (rc) return rc;

@@ -690,6 +690,9 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 // A 512-byte row is too small for one wave: 16 lanes own a row (8 columns each), a wave walks 4 rows at once and
 // both of its row quartets are loaded up front; row statistics are 4-step xor-shuffles inside the 16-lane group;
 // the P/Q column accumulators (see the wide kernel) are folded over the row slots with two more shuffles.
+// XF: x is fp32 (else bf16); DRES: fp32 residual gradient present; F32 / B16: which outputs exist -- compile-time, so
+// that every load / store is unconditional straight-line code.
+template <bool XF, bool DRES, bool F32, bool B16>
 __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a) {
   constexpr int D = 128;
   __shared__ float red[16][2][D];
@@ -715,7 +718,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
     const int row = r_begin + it * 16 + w * 4 + sub;
     valid[it] = row < a.f.rows;
     const size_t off = (size_t)(valid[it] ? row : 0) * D + c0;
-    if (a.f.x) {
+    if constexpr (XF) {
       const float4 t0 = *reinterpret_cast<const float4*>(a.f.x + off), t1 = *reinterpret_cast<const float4*>(a.f.x + off + 4);
       x[it][0] = t0.x; x[it][1] = t0.y; x[it][2] = t0.z; x[it][3] = t0.w; x[it][4] = t1.x; x[it][5] = t1.y; x[it][6] = t1.z; x[it][7] = t1.w;
     } else {
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
       for (int i = 0; i < 8; ++i) x[it][i] = bf2f(t[i]);
     }
     dyb[it] = *reinterpret_cast<const bf16x8_t*>(a.dout + off);
-    if (a.dres) {
+    if constexpr (DRES) {
       const float4 t0 = *reinterpret_cast<const float4*>(a.dres + off), t1 = *reinterpret_cast<const float4*>(a.dres + off + 4);
       r[it][0] = t0.x; r[it][1] = t0.y; r[it][2] = t0.z; r[it][3] = t0.w; r[it][4] = t1.x; r[it][5] = t1.y; r[it][6] = t1.z; r[it][7] = t1.w;
     }
@@ -763,14 +766,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
     t2 = sum16(t2) * (1.0f / D);
     float dx[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dx[i] = rstd * (dxh[i] - t1 - xh[i] * t2) + (a.dres ? r[it][i] : 0.f);
+    for (int i = 0; i < 8; ++i) dx[i] = rstd * (dxh[i] - t1 - xh[i] * t2) + (DRES ? r[it][i] : 0.f);
     if (valid[it]) {
       const size_t off = (size_t)row * D + c0;
-      if (a.dx_f32) {
+      if constexpr (F32) {
         *reinterpret_cast<float4*>(a.dx_f32 + off) = make_float4(dx[0], dx[1], dx[2], dx[3]);
         *reinterpret_cast<float4*>(a.dx_f32 + off + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
       }
-      if (a.dx_bf16) {
+      if constexpr (B16) {
         bf16x8_t o;
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = f2bf(dx[i]);
@@ -937,7 +940,22 @@ int launch_layernorm_bwd(const LnBwdArgs& a, hipStream_t st) {
   d.partial = a.partial;
   d.group_rows = gr;
   if (a.f.D == 128 && !a.f.film_scale && !a.f.swish && gr == 32 && smd_tuning_get("ln_bwd_narrow")) {
-    hipLaunchKernelGGL(layernorm_bwd_narrow128_kernel, dim3(ngroups), dim3(256), 0, st, d);
+    // the engine's three uses: fp32 x, residual or not, fp32 + bf16 outputs or bf16 only
+#define SMD_NARROW(XF_, DR_, F_, B_) hipLaunchKernelGGL((layernorm_bwd_narrow128_kernel<XF_, DR_, F_, B_>), dim3(ngroups), dim3(256), 0, st, d)
+    const int key = (d.f.x ? 8 : 0) | (d.dres ? 4 : 0) | (d.dx_f32 ? 2 : 0) | (d.dx_bf16 ? 1 : 0);
+    switch (key) {
+      case 15: SMD_NARROW(true, true, true, true); break;
+      case 11: SMD_NARROW(true, false, true, true); break;
+      case 9: SMD_NARROW(true, false, false, true); break;
+      case 14: SMD_NARROW(true, true, true, false); break;
+      case 10: SMD_NARROW(true, false, true, false); break;
+      case 13: SMD_NARROW(true, true, false, true); break;
+      case 7: SMD_NARROW(false, true, true, true); break;
+      case 3: SMD_NARROW(false, false, true, true); break;
+      case 1: SMD_NARROW(false, false, false, true); break;
+      default: SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st)); break;
+    }
+#undef SMD_NARROW
   } else {
     SMD_LN_DISPATCH(a.f.D, run_bwd, (d, ngroups, st));
   }

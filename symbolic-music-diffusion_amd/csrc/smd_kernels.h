@@ -61,6 +61,11 @@ struct TnLaunch {
   int tr_path = 1;
 };
 size_t gemm_tn_slab_elems();
+// Weight-gradient GEMMs normally run on the engine's side stream next to the backward chain.  Small LayerNorm-backward
+// workgroups that SHARED A CU with their workgroups lost bitwise repeatability (established by
+// exclusion experiments, mechanism unknown), so by default (knob "tn_exclusive_cu" = 1) every weight-gradient workgroup is
+// launched with a dynamic-LDS pad that fills the CU's 160 KiB: no other LDS-using workgroup can be resident beside it.
+int smd_tn_pad_bytes(int static_lds_bytes);
 // 256x256 8-phase wgrad kernel (gemm_tn256.hip): plan returns nsplit (0 = not eligible)
 int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split);
 int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st);
@@ -138,11 +143,44 @@ int launch_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float*
                          const bf16_t* W1t, const float* b1, const bf16_t* W2t, const float* b2, int M, bf16_t* save_a2,
                          bf16_t* save_z1, bf16_t* save_u, hipStream_t st);
 
+// The MLP half-layer with the hidden dimension split over workgroups (4 quarters x groups of 4 / 2 / 1 samples: a
+// quarter of the weight stream per CU).  Input a2 = ln2(h_mid) in bf16 (emitted by launch_attn_block_fwd); output four
+// fp32 partial tiles part[k] = part + k * rows * 128 with h_out = (p0 + p1) + (p2 + p3) (quarter 0 carries b2 and the
+// residual h_res), summed by the consumer: the next attention kernel or launch_ln128_parts.  Needs M % 512 == 0.
+int mlp_hs_samples_per_group(int rows, int M);          // 4 / 2 / 1, or 0 when the shape is not supported
+int launch_mlp_block_fwd_hs(const bf16_t* a2, const float* h_res, int rows, const bf16_t* W1t, const float* b1,
+                            const bf16_t* W2t, const float* b2, int M, float* part, hipStream_t st);
+// x = (p0 + p1) + (p2 + p3) per 128-wide row; x_out (nullable) <- x; ln_out (nullable) <- LayerNorm(x) in bf16
+int launch_ln128_parts(const float* parts, size_t part_stride, int rows, const float* gamma, const float* beta, float* x_out,
+                       bf16_t* ln_out, hipStream_t st);
+
+// Backward of the MLP half-layer with the hidden activations recomputed from a2 (nothing but a2 saved by the forward):
+// writes u = gelu(a2 W1 + b1) and dz = (dh W2^T) * gelu'(.) ([rows][M] bf16: operands of the two weight gradients) and
+// four fp32 partial tiles of da2 = dz W1^T.  W1t [M][128] / W2 [M][128] / W1 [128][M]: fc1 forward pack, fc2 and fc1
+// dgrad packs.  rows % 128 == 0, M % 512 == 0.
+int launch_mlp_block_bwd_hs(const bf16_t* a2, const bf16_t* dh, int rows, const bf16_t* W1t, const bf16_t* W2, const bf16_t* W1,
+                            const float* b1, int M, bf16_t* u, bf16_t* dz, float* part, hipStream_t st);
+// LayerNorm (D = 128) backward on dout = (p0 + p1) + (p2 + p3): dx = LN-bwd + dres -> fp32 (may alias dres) / bf16;
+// partial: [rows/32][2][128] dgamma / dbeta group sums (reduced by launch_ln_bwd_reduce_batched)
+int launch_ln128_bwd_parts(const float* x, const float* parts, size_t part_stride, int rows, const float* gamma, const float* dres,
+                           float* dx_f32, bf16_t* dx_bf16, float* partial, hipStream_t st);
+
+// optional extras of the attention half-layer kernel: partial-sum input and the ln2 of its output
+struct AttnBlockExtra {
+  const float* h_parts = nullptr;   // input x = (p0 + p1) + (p2 + p3), parts h_parts + k * part_stride (h_in unused)
+  size_t part_stride = 0;
+  float* h_comb = nullptr;          // x written out (nullable)
+  const float* gamma2 = nullptr;    // LayerNorm of the output rows -> a2_out (bf16 [rows][128], nullable)
+  const float* beta2 = nullptr;
+  bf16_t* a2_out = nullptr;
+};
+
 // h_out = h_in + out_proj(attention(qkv(LN(h_in)))), S = 32 tokens per sample, E = 128; Wqkv_t [384][128]
 // (q | k | v rows, head h = rows h*d..), Wo_t [128][128]; optional saves: a1 = LN output, qkv (q unscaled), o
 int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta,
                           const bf16_t* Wqkv_t, const float* b_qkv, const bf16_t* Wo_t, const float* b_o, int num_heads,
-                          bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st);
+                          bf16_t* save_a1, bf16_t* save_qkv, bf16_t* save_o, hipStream_t st,
+                          const AttnBlockExtra* extra = nullptr);
 
 // backward of the same half-layer between the two LayerNorms: dqkv (written for the qkv wgrad) and da1 = gradient
 // wrt the LN1 output, from dh_mid (bf16), the saved qkv and the dgrad operand packs Wo [128][128], Wqkv [128][384]

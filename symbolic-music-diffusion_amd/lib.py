@@ -79,6 +79,12 @@ _SIGS = {
                                    c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
     "smd_mlp_block_fwd": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, c_void,
                                     c_void, c_void, c_void]),
+    "smd_mlp_block_fwd_hs": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, C.c_int, c_void, c_void]),
+    "smd_mlp_block_bwd_hs": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, C.c_int, c_void, c_void, c_void, c_void]),
+    "smd_ln128_bwd_parts": (C.c_int, [c_void, c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void]),
+    "smd_ln128_parts": (C.c_int, [c_void, c_i64, C.c_int, c_void, c_void, c_void, c_void, c_void]),
+    "smd_attn_block_fwd_ex": (C.c_int, [c_void, c_void, c_i64, c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void,
+                                        c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void]),
     "smd_attn_block_fwd": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, c_void,
                                      c_void, c_void, c_void]),
     "smd_attn_block_bwd": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
@@ -123,7 +129,7 @@ def get_lib() -> C.CDLL:
     if _LIB is not None:
         return _LIB
     path = _build.LIB_PATH
-    if _build.is_stale():
+    if _build.is_stale() and not (os.environ.get("SMD_LIB_SUFFIX") and os.path.exists(path)):   # experiment builds are never rebuilt implicitly
         try:
             _build.build_library(verbose=False)
         except Exception as e:  # no hipcc, or compile failure

@@ -269,6 +269,138 @@ def test_mlp_block_fwd_fused(L, dev, rows, M):
     assert torch.equal(inpl, out)
 
 
+@pytest.mark.parametrize("rows,M", [(32, 512), (192, 1024), (128, 2048), (8192, 2048)])
+def test_mlp_block_fwd_hidden_split(L, dev, rows, M):
+    """mlp_hs_fwd (4 hidden quarters x groups of 4 / 2 / 1 samples -> four fp32 partial tiles) + ln128_parts (their
+    fixed-order sum and the LayerNorm of it) vs fp64 with the kernel's bf16 rounding of the GELU output; repeatable."""
+    g = torch.Generator().manual_seed(rows + M + 1)
+    h = torch.randn(rows, 128, generator=g) * 1.5 + 0.3
+    a2 = bf(torch.randn(rows, 128, generator=g))
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)
+    W1 = bf(torch.randn(128, M, generator=g) * 0.09)
+    b1 = 0.1 * torch.randn(M, generator=g)
+    W2 = bf(torch.randn(M, 128, generator=g) * (1.0 / math.sqrt(M)))
+    b2 = 0.1 * torch.randn(128, generator=g)
+    hd = h.double()
+    z = a2.double() @ W1.double() + b1.double()
+    u = bf(O.gelu(z).float())
+    ref = hd + u.double() @ W2.double() + b2.double()
+    mu, var = ref.mean(-1, keepdim=True), ref.var(-1, unbiased=False, keepdim=True)
+    ln_ref = (ref - mu) / torch.sqrt(var + 1e-6) * gamma.double() + beta.double()
+    hD, a2D, gD, bD = h.to(dev), a2.to(dev), gamma.to(dev), beta.to(dev)
+    W1t, W2t = W1.t().contiguous().to(dev), W2.t().contiguous().to(dev)
+    b1D, b2D = b1.to(dev), b2.to(dev)
+    outs = []
+    for rep in range(3):
+        part = torch.full((4, rows, 128), float("nan"), device=dev)
+        ck(L, L.smd_mlp_block_fwd_hs(P(a2D), P(hD), rows, P(W1t), P(b1D), P(W2t), P(b2D), M, P(part), st()))
+        xo = torch.full((rows, 128), float("nan"), device=dev)
+        lo = torch.zeros(rows, 128, dtype=torch.bfloat16, device=dev)
+        ck(L, L.smd_ln128_parts(P(part), rows * 128, rows, P(gD), P(bD), P(xo), P(lo), st()))
+        outs.append((part, xo, lo))
+    torch.cuda.synchronize()
+    part, xo, lo = outs[0]
+    assert torch.equal(xo, (part[0] + part[1]) + (part[2] + part[3]))
+    e_out = rel(xo.double().cpu() - hd, ref - hd)
+    e_ln = rel(lo.float(), ln_ref)
+    print(f"mlp_block_fwd_hs rows={rows} M={M}: delta rel {e_out:.2e}; ln(x) rel {e_ln:.2e}")
+    assert e_out < 3e-3 and e_ln < 4e-3
+    for k in (1, 2):
+        assert torch.equal(outs[k][0], part) and torch.equal(outs[k][2], lo)
+
+
+@pytest.mark.parametrize("rows,M", [(128, 512), (256, 2048), (8192, 2048)])
+def test_mlp_block_bwd_hidden_split(L, dev, rows, M):
+    """mlp_hs_bwd (recompute) vs fp64: u = gelu(a2 W1 + b1), dz = (dh W2^T) gelu'(z) (bf16 outputs) and da2 = dz W1^T as
+    the fixed-order sum of the four partial tiles; then ln128_bwd_parts on those tiles vs fp64 autograd of LayerNorm."""
+    g = torch.Generator().manual_seed(rows + M + 3)
+    a2 = bf(torch.randn(rows, 128, generator=g))
+    dh = bf(torch.randn(rows, 128, generator=g) * 0.05)
+    W1 = bf(torch.randn(128, M, generator=g) * 0.09)          # fc1 kernel (in 128, out M)
+    b1 = 0.1 * torch.randn(M, generator=g)
+    W2 = bf(torch.randn(M, 128, generator=g) * (1.0 / math.sqrt(M)))   # fc2 kernel (in M, out 128)
+    z = (a2.double() @ W1.double() + b1.double()).requires_grad_(True)
+    u_ref = O.gelu(z)
+    (gz,) = torch.autograd.grad(u_ref.sum(), z)                # gelu'(z)
+    du = dh.double() @ W2.double().t()
+    dz_ref = du * gz
+    da2_ref = bf(dz_ref.float()).double() @ W1.double().t()    # the kernel contracts the bf16-rounded dz
+    a2D, dhD = a2.to(dev), dh.to(dev)
+    W1t = W1.t().contiguous().to(dev)                          # [M][128] forward pack of fc1
+    W2p = W2.contiguous().to(dev)                              # [M][128] dgrad pack of fc2
+    W1p = W1.contiguous().to(dev)                              # [128][M] dgrad pack of fc1
+    b1D = b1.to(dev)
+    res = []
+    for rep in range(2):
+        u = torch.zeros(rows, M, dtype=torch.bfloat16, device=dev)
+        dz = torch.zeros(rows, M, dtype=torch.bfloat16, device=dev)
+        part = torch.full((4, rows, 128), float("nan"), device=dev)
+        ck(L, L.smd_mlp_block_bwd_hs(P(a2D), P(dhD), rows, P(W1t), P(W2p), P(W1p), P(b1D), M, P(u), P(dz), P(part), st()))
+        res.append((u, dz, part))
+    torch.cuda.synchronize()
+    u, dz, part = res[0]
+    da2 = ((part[0] + part[1]) + (part[2] + part[3])).double().cpu()
+    e_u, e_dz, e_da = rel(u.float(), u_ref.detach()), rel(dz.float(), dz_ref.detach()), rel(da2, da2_ref.detach())
+    print(f"mlp_block_bwd_hs rows={rows} M={M}: u {e_u:.2e} dz {e_dz:.2e} da2 {e_da:.2e}")
+    assert e_u < 4e-3 and e_dz < 6e-3 and e_da < 4e-3
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(res[0], res[1]))
+    # ---- ln2 backward on the partial tiles
+    x = torch.randn(rows, 128, generator=g) * 1.3 + 0.2
+    gamma = 1 + 0.2 * torch.randn(128, generator=g)
+    dres = 0.05 * torch.randn(rows, 128, generator=g)
+    xd = x.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = torch.zeros(128, dtype=torch.float64, requires_grad=True)
+    mu, var = xd.mean(-1, keepdim=True), xd.var(-1, unbiased=False, keepdim=True)
+    y = (xd - mu) / torch.sqrt(var + 1e-6) * gd + bd
+    dout = ((part[0] + part[1]) + (part[2] + part[3])).double().cpu()
+    y.backward(dout)
+    dx_ref = xd.grad + dres.double()
+    xD, gD, rD = x.to(dev), gamma.to(dev), dres.to(dev)
+    partial = torch.zeros(rows // 32, 2, 128, device=dev)
+    dxb = torch.zeros(rows, 128, dtype=torch.bfloat16, device=dev)
+    inpl = rD.clone()
+    ck(L, L.smd_ln128_bwd_parts(P(xD), P(part), rows * 128, rows, P(gD), P(inpl), P(inpl), P(dxb), P(partial), st()))
+    torch.cuda.synchronize()
+    e_dx, e_dxb = rel(inpl, dx_ref), rel(dxb.float(), dx_ref)
+    e_g, e_b = rel(partial[:, 0].sum(0), gd.grad), rel(partial[:, 1].sum(0), bd.grad)
+    print(f"ln128_bwd_parts rows={rows}: dx {e_dx:.2e} (bf16 {e_dxb:.2e}) dgamma {e_g:.2e} dbeta {e_b:.2e}")
+    assert e_dx < 2e-5 and e_dxb < 4e-3 and e_g < 2e-5 and e_b < 2e-5
+
+
+@pytest.mark.parametrize("rows,H", [(64, 8), (8192, 16)])
+def test_attn_block_fwd_partial_sum_input_and_ln2(L, dev, rows, H):
+    """smd_attn_block_fwd_ex: the input given as four partial tiles must give bitwise the result of the plain call on
+    their fixed-order sum; the emitted a2 must be the LayerNorm of the output rows."""
+    g = torch.Generator().manual_seed(rows + H + 7)
+    E = 128
+    parts = torch.randn(4, rows, E, generator=g) * 0.7
+    gamma, beta = 1 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    gamma2, beta2 = 1 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    Wqkv_t = bf(torch.randn(3 * E, E, generator=g) * 0.12).to(dev)
+    bqkv = (0.1 * torch.randn(3 * E, generator=g)).to(dev)
+    Wo_t = bf(torch.randn(E, E, generator=g) * 0.09).to(dev)
+    bo = (0.1 * torch.randn(E, generator=g)).to(dev)
+    pD, gD, bD, g2D, b2D = parts.to(dev), gamma.to(dev), beta.to(dev), gamma2.to(dev), beta2.to(dev)
+    x = (pD[0] + pD[1]) + (pD[2] + pD[3])
+    plain = torch.empty(rows, E, device=dev)
+    ck(L, L.smd_attn_block_fwd(P(x), P(plain), rows, P(gD), P(bD), P(Wqkv_t), P(bqkv), P(Wo_t), P(bo), H, None, None, None, st()))
+    out = torch.empty(rows, E, device=dev)
+    comb = torch.empty(rows, E, device=dev)
+    a2 = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    ck(L, L.smd_attn_block_fwd_ex(None, P(pD), rows * E, P(comb), P(out), rows, P(gD), P(bD), P(Wqkv_t), P(bqkv), P(Wo_t), P(bo), H,
+                                  P(g2D), P(b2D), P(a2), None, None, None, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(comb, x)
+    assert torch.equal(out, plain)
+    od = out.double().cpu()
+    mu, var = od.mean(-1, keepdim=True), od.var(-1, unbiased=False, keepdim=True)
+    ln = (od - mu) / torch.sqrt(var + 1e-6) * gamma2.double() + beta2.double()
+    e = rel(a2.float(), ln)
+    print(f"attn_block_fwd_ex rows={rows} H={H}: a2 rel {e:.2e}")
+    assert e < 4e-3
+
+
 @pytest.mark.parametrize("rows,H", [(32, 8), (96, 16), (64, 4), (8192, 8)])
 def test_attn_block_fwd_fused(L, dev, rows, H):
     """Fused LN + QKV + attention + out_proj + residual (encoder_fused.hip) vs the fp64 oracle attention with the

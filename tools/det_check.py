@@ -55,7 +55,7 @@ def plan_offsets(B=256, S=32, C=512, Cp=512, E=128, M=2048, F=128, L=6, K=2):
         off = (off + 255) // 256 * 256
         out.append((name, off, nbytes))
         off += nbytes
-    take("zero_page", 256); take("step_arrive", 256); take("x_bf16", R * Cp * 2); take("pe", S * E * 4); take("pred", R * C * 4); take("s", B * 4)
+    take("zero_page", 256); take("step_arrive", 256); take("mlp_part", 4 * R * E * 4); take("x_bf16", R * Cp * 2); take("pe", S * E * 4); take("pred", R * C * 4); take("s", B * 4)
     for l in range(L):
         take(f"h[{l}]", R * E * 4); take(f"h_mid[{l}]", R * E * 4); take(f"a1[{l}]", R * E * 2); take(f"qkv[{l}]", R * 3 * E * 2)
         take(f"o[{l}]", R * E * 2); take(f"a2[{l}]", R * E * 2); take(f"z1[{l}]", R * M * 2); take(f"u[{l}]", R * M * 2)
