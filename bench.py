@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--rng-impl", choices=["philox", "threefry"], default="philox",
                     help="noise streams: in-kernel Philox (default) or jax.random-compatible threefry2x32 draws")
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: OCP e4m3 operands with per-row E8M0 scales for the DenseResBlock forward GEMMs (BASELINE config 5)")
     ap.add_argument("--no-roofline-microbench", action="store_true",
                     help="skip the back-to-back launches of the dominant kernel (profiling runs: the trace then holds the timed loops only)")
     return ap.parse_args()
@@ -131,7 +133,7 @@ def main():
         k, _, v = kv.partition("=")
         lib.check(lib.get_lib().smd_set_tuning(k.encode(), int(v)))
     kw = dict() if a.config == "base" else dict(num_layers=8, num_heads=16, num_mlp_layers=3)
-    cfg = NetConfig(architecture="TransformerDDPM", data_channels=512, seq_len=32, num_timesteps=1000, **kw)
+    cfg = NetConfig(architecture="TransformerDDPM", data_channels=512, seq_len=32, num_timesteps=1000, dtype=a.dtype, **kw)
     model = N.Model(cfg, dev, seed=0)
     betas = S.create_noise_schedule(1e-6, 0.01, 1000, "linear")
     B = a.batch
@@ -335,7 +337,7 @@ def main():
             "value": round(world * n_eval / total, 3), "unit": "denoising-steps/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * total / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 DenseResBlock forward GEMMs) + bf16", "data": "synthetic",
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,

@@ -140,6 +140,20 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
  *               2 = also on small grids (tests). */
 int smd_set_tuning(const char* key, int value);
 
+/* ---- e4m3 (OCP fp8) path: BASELINE config 5.  Operands are e4m3 bytes with one power-of-two (E8M0) scale per row,
+ * contracted by v_mfma_scale_f32_32x32x64_f8f6f4; engine option "fp8" = 1 (before bind_workspace) routes the
+ * DenseResBlock forward GEMMs (models/shared.py:65,69) through it. ------------------------------------------------ */
+/* rows of a bf16 matrix [rows][ld] (K used) -> out8 [rows][K] e4m3(v * 2^-e), scale[rows] = E8M0 byte e + 127 */
+int smd_quantize_rows_e4m3(const smd_bf16* in, int ld, int rows, int K, uint8_t* out8, uint32_t* scale, void* stream);
+/* C[M,N] = (2^sa[m] A8[m,:]) . (2^sb[n] Bt8[n,:]) + bias (+ fp32 residual) -> fp32 and/or bf16; M, N, K % 256 == 0 */
+int smd_gemm_e4m3_nt(const uint8_t* A8, int lda, const uint32_t* scale_a, const uint8_t* Bt8, int ldb,
+                     const uint32_t* scale_b, int M, int N, int K, const float* bias, const float* residual, int ld_res,
+                     float* out_f32, int ld_out, smd_bf16* out_bf16, int ld_outb, void* stream);
+/* smd_layernorm_fwd (D = 1024 / 2048, FiLM + swish or neither) writing the e4m3 copy + row scales (and bf16 if non-NULL) */
+int smd_layernorm_fwd_e4m3(const float* x, int rows, int D, const float* gamma, const float* beta, const float* film_scale,
+                           const float* film_shift, int ld_film, int rows_per_sample, int swish, uint8_t* out8,
+                           uint32_t* out_scale, smd_bf16* out_bf16 /*nullable*/, void* stream);
+
 /* ---- single kernels (unit-testable ops) ------------------------------------------------------- */
 enum { SMD_EPI_NONE = 0, SMD_EPI_GELU = 1, SMD_EPI_SWISH = 2 };
 /* C[M,N] = act(A[M,K] Bt[N,K]^T + bias) (+ residual); nn.Dense, models/ncsn.py:155 etc. */

@@ -38,7 +38,7 @@ def load_model(FLAGS, shape, device):
     rng = ncsn.make_key(FLAGS.sample_seed, FLAGS.rng_impl)
     rng, model_rng = ncsn.split(rng)
     model = ncsn.create_model(model_rng, shape, model_kwargs, batch_size=1, verbose=True,
-                              architecture=FLAGS.architecture, num_timesteps=FLAGS.num_sigmas, device=device)
+                              architecture=FLAGS.architecture, num_timesteps=FLAGS.num_sigmas, device=device, dtype=FLAGS.dtype)
     found = (checkpoint.load_ema_params if FLAGS.sample_ema else
              lambda d, e: checkpoint.restore_checkpoint(d, e, load_optimizer_state=False)[0])(FLAGS.model_dir, model.engine)
     if not found:

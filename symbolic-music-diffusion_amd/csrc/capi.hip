@@ -88,6 +88,8 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   if (std::string(key) == "mlp_hs") { e->impl.mlp_hs = value ? 1 : 0; return 0; }
+  if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
+  if (std::string(key) == "w8_dirty") { e->impl.mark_w8_dirty(); return 0; }   // the bf16 operand pack changed under another handle
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;
 }
@@ -157,6 +159,26 @@ int smd_gemm_bf16_nt(const smd_bf16* A, int lda, const smd_bf16* Bt, int ldb, in
   ep.bias = bias; ep.act = act; ep.res_f32 = residual; ep.ld_res = ld_res;
   ep.out_f32 = out_f32; ep.ld_out = ld_out; ep.out_bf16 = B(out_bf16); ep.ld_outb = ld_outb;
   return launch_gemm_nt(B(A), lda, B(Bt), ldb, M, N, K, ep, S(stream));
+}
+int smd_quantize_rows_e4m3(const smd_bf16* in, int ld, int rows, int K, uint8_t* out8, uint32_t* scale, void* stream) {
+  return launch_quantize_rows_e4m3(B(in), ld, rows, K, out8, scale, S(stream));
+}
+int smd_gemm_e4m3_nt(const uint8_t* A8, int lda, const uint32_t* scale_a, const uint8_t* Bt8, int ldb, const uint32_t* scale_b, int M,
+                     int N, int K, const float* bias, const float* residual, int ld_res, float* out_f32, int ld_out,
+                     smd_bf16* out_bf16, int ld_outb, void* stream) {
+  GemmEpilogue ep;
+  ep.bias = bias; ep.res_f32 = residual; ep.ld_res = ld_res; ep.out_f32 = out_f32; ep.ld_out = ld_out; ep.out_bf16 = B(out_bf16);
+  ep.ld_outb = ld_outb;
+  return launch_gemm_nt256_fp8(A8, lda, scale_a, Bt8, ldb, scale_b, M, N, K, ep, S(stream));
+}
+int smd_layernorm_fwd_e4m3(const float* x, int rows, int D, const float* gamma, const float* beta, const float* film_scale,
+                           const float* film_shift, int ld_film, int rows_per_sample, int swish, uint8_t* out8, uint32_t* out_scale,
+                           smd_bf16* out_bf16, void* stream) {
+  LnArgs a;
+  a.x = x; a.rows = rows; a.D = D; a.gamma = gamma; a.beta = beta; a.film_scale = film_scale; a.film_shift = film_shift;
+  a.ld_film = ld_film; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.swish = swish; a.out = B(out_bf16);
+  a.out_f8 = out8; a.out_scale = out_scale;
+  return launch_layernorm_fwd(a, S(stream));
 }
 int smd_mlp_block_fwd(const float* h_in, float* h_out, int rows, const float* gamma, const float* beta, const smd_bf16* W1t,
                       const float* b1, const smd_bf16* W2t, const float* b2, int hidden, smd_bf16* save_a2, smd_bf16* save_z1,

@@ -109,6 +109,7 @@ class SmdEngine {
   // dgrad / LayerNorm chain.  Every gradient buffer a side wgrad reads has its own slot (no reuse inside a
   // step); the side stream is joined at the end of loss_backward().  0 = single stream.
   int set_side_stream(int enable);
+  void mark_w8_dirty() { w8_dirty_ = true; }
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
@@ -118,6 +119,9 @@ class SmdEngine {
   int resgrad_bf16 = 1;   // ResBlock residual-gradient chain kept in bf16 (the GEMM operand copy) instead of fp32 + bf16
   int fused_encoder = 1;                                      // encoder_fused.hip half-layer kernels (0: separate launches)
   int side_wgrad = 0;
+  // e4m3 (OCP fp8) operands with per-row E8M0 scales for the DenseResBlock GEMMs of the FORWARD pass (77 % of its flops),
+  // v_mfma_scale_f32_32x32x64_f8f6f4; everything else, and the whole backward pass, stays bf16.  Set before bind_workspace.
+  int fp8 = 0;
   int mlp_hs = 1;              // hidden-split fused MLP half-layers (forward; backward with recompute); 0: the older paths
 
  private:
@@ -168,6 +172,7 @@ class SmdEngine {
   std::vector<hipEvent_t> events_;             // recycled per loss_backward
   size_t next_event_ = 0;
   bool side_pending_ = false;
+  bool w8_dirty_ = true;                       // the e4m3 weight copies are older than the bf16 operand pack
   bool hs_train_ = false;                      // the forward pass of this step used the hidden-split MLP dataflow
   hipEvent_t take_event();
 
@@ -185,6 +190,10 @@ class SmdEngine {
     // output stage
     std::vector<float*> y;                // [R][M] trunk (K+1 in training, 1 in inference)
     std::vector<bf16_t*> ya1, o1, ya2;
+    std::vector<unsigned char*> ya1_f8, ya2_f8;   // e4m3 copies of the two FiLM-LayerNorm outputs + row scales (fp8 mode)
+    std::vector<uint32_t*> sa1, sa2;
+    unsigned char* w8 = nullptr;          // [K blocks][r1, r2][M][M] e4m3 weights (rows = output features)
+    uint32_t* w8s = nullptr;              // [K blocks][r1, r2][M] row scales
     bf16_t* ao = nullptr;
     bf16_t* emb = nullptr;                // [B][F]
     std::vector<bf16_t*> zf1, f1, p;      // [B][4F]

@@ -274,6 +274,17 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     t.p[k] = c.take<bf16_t>(B * 4 * F);
     t.ss[k] = c.take<float>(B * 2 * M);
   }
+  if (fp8) {
+    t.ya1_f8.resize(nk); t.ya2_f8.resize(nk); t.sa1.resize(nk); t.sa2.resize(nk);
+    for (int k = 0; k < nk; ++k) {
+      t.ya1_f8[k] = c.take<unsigned char>(R * M);
+      t.ya2_f8[k] = training ? c.take<unsigned char>(R * M) : t.ya1_f8[k];
+      t.sa1[k] = c.take<uint32_t>(R);
+      t.sa2[k] = training ? c.take<uint32_t>(R) : t.sa1[k];
+    }
+    t.w8 = c.take<unsigned char>((size_t)K * 2 * M * M);
+    t.w8s = c.take<uint32_t>((size_t)K * 2 * M);
+  }
   t.ao = training ? c.take<bf16_t>(R * M) : t.ya1[0];
   t.emb = c.take<bf16_t>(B * F);
   if (training) {
@@ -341,6 +352,7 @@ int SmdEngine::bind_workspace(void* ws, int64_t bytes, int batch, int training, 
   SMD_ARG_CHECK(bytes >= need, "bind_workspace: %lld bytes given, %lld needed", (long long)bytes, (long long)need);
   plan(ws, batch, training, &W);
   batch_ = batch; training_ = training;
+  w8_dirty_ = true;
   hipError_t e = hipMemsetAsync(ws, 0, (size_t)need, st);   // zero pads / zero page / padded operand columns
   if (e != hipSuccess) { smd_set_error("bind_workspace: memset: %s", hipGetErrorString(e)); return (int)e; }
   if (d_.arch == 0) RC(launch_pos_encoding(W.pe, d_.seq_len, d_.embed_channels, st));
@@ -355,6 +367,7 @@ int SmdEngine::bind_schedule(const float* coef, const float* sqrt_ap, const floa
 
 int SmdEngine::refresh_weights(hipStream_t st) {
   SMD_ARG_CHECK(params_ && wpack_, "refresh_weights: parameters not bound");
+  w8_dirty_ = true;
   size_t i = 0;
   while (i < all_dense_.size()) {                 // one launch per <= SMD_RECAST_MAX weights (normally one)
     RecastTable t;
@@ -484,6 +497,16 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
   // 173-175 / 130-132).  Per-sample noise levels generate scale/shift here; the sampler reads the
   // per-timestep tables built by prepare_sampler() instead.
   if (!t_ptr) RC(launch_noise_embed(W.s, B, F, W.emb, F, st));
+  const bool f8 = fp8 && W.w8 && R % 256 == 0 && M % 256 == 0 && (M == 1024 || M == 2048);
+  if (f8 && w8_dirty_) {           // e4m3 copies of the ResBlock weights (per output row), once per weight refresh
+    for (int k = 0; k < K; ++k) {
+      const FilmResP& b = blk_[k];
+      RC(launch_quantize_rows_e4m3(wpack_ + b.r1.Wt_off, b.r1.Kp, M, M, W.w8 + (size_t)k * 2 * M * M, W.w8s + (size_t)k * 2 * M, st));
+      RC(launch_quantize_rows_e4m3(wpack_ + b.r2.Wt_off, b.r2.Kp, M, M, W.w8 + (size_t)k * 2 * M * M + (size_t)M * M,
+                                   W.w8s + (size_t)k * 2 * M + M, st));
+    }
+    w8_dirty_ = false;
+  }
   for (int k = 0; k < K; ++k) {
     const int i = tr ? k : 0;
     const FilmResP& b = blk_[k];
@@ -504,6 +527,22 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
     LnArgs ln;
     ln.rows = R; ln.D = M; ln.film_scale = scale; ln.film_shift = scale + M; ln.ld_film = ld_film;
     ln.rows_per_sample = S; ln.t_ptr = t_ptr; ln.swish = 1;
+    if (f8) {
+      // e4m3 forward GEMMs: the LayerNorm writes the A operand as e4m3 + row scales (and, when training, the bf16 copy
+      // the weight gradient contracts), the weights were quantised per output row above
+      const size_t wo = (size_t)k * 2 * M * M, so = (size_t)k * 2 * M;
+      ln.x = y_in; ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off);
+      ln.out = tr ? W.ya1[i] : nullptr; ln.out_f8 = W.ya1_f8[i]; ln.out_scale = W.sa1[i];
+      RC(launch_layernorm_fwd(ln, st));
+      { GemmEpilogue ep; ep.bias = P(b.r1.b_off); ep.out_bf16 = W.o1[i]; ep.ld_outb = M;
+        RC(launch_gemm_nt256_fp8(W.ya1_f8[i], M, W.sa1[i], W.w8 + wo, M, W.w8s + so, R, M, M, ep, st)); }
+      ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off);
+      ln.out = tr ? W.ya2[i] : nullptr; ln.out_f8 = W.ya2_f8[i]; ln.out_scale = W.sa2[i];
+      RC(launch_layernorm_fwd(ln, st));
+      { GemmEpilogue ep; ep.bias = P(b.r2.b_off); ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M;
+        RC(launch_gemm_nt256_fp8(W.ya2_f8[i], M, W.sa2[i], W.w8 + wo + (size_t)M * M, M, W.w8s + so + M, R, M, M, ep, st)); }
+      continue;
+    }
     ln.x = y_in; ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off); ln.out = W.ya1[i];
     RC(launch_layernorm_fwd(ln, st));
     { GemmEpilogue ep; ep.out_bf16 = W.o1[i]; ep.ld_outb = M; RC(dense_fwd(b.r1, W.ya1[i], M, R, ep, st)); }

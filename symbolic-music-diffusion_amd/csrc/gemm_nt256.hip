@@ -28,6 +28,8 @@
 #include "smd_kernels.h"
 #include "gemm_epilogue.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 64;
@@ -60,6 +62,12 @@ struct Frags {
   bf16x8_t a[2][4];    // [m-tile][k-step] of the current A half
   bf16x8_t b0[4], b1[4];
 };
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+struct Frags8 {        // e4m3 operands: one 8-register tuple per 64-wide step = the two 16-byte chunks of its two K-blocks
+  i32x8_t a[2][2];     // [m-tile][64-wide step]
+  i32x8_t b0[2], b1[2];
+};
 
 // `ad[ks]` = LDS address of the lane's chunk for k-step ks in the wave's first row block of a K-tile buffer;
 // `off` (half-tile offset) and the m-tile stride fold into the ds_read immediate (< 64 KiB).
@@ -73,13 +81,45 @@ __device__ __forceinline__ void read_b(bf16x8_t (&b)[4], const lds_byte_ptr (&ad
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<lds_frag_ptr>(ad[ks] + off);
 }
+// e4m3: ad[ks] (ks = 0, 1) = address of the lane's 32 contiguous bytes of 64-wide step ks.  Read as two bf16x8-typed
+// 16-byte loads like the bf16 kernel's (with an int-typed 32-byte load hipcc orders every ds_read behind ALL outstanding
+// LDS-DMA -- s_waitcnt vmcnt(0) in every phase, which serialises the pipeline) and joined in registers.
+__device__ __forceinline__ i32x8_t join8(const bf16x8_t lo, const bf16x8_t hi) {
+  return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ void read_a(Frags8& f, const lds_byte_ptr (&ad)[4], int off) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      f.a[mt][ks] = join8(*reinterpret_cast<lds_frag_ptr>(ad[ks] + off + mt * 32 * 128), *reinterpret_cast<lds_frag_ptr>(ad[ks] + off + mt * 32 * 128 + 16));
+}
+__device__ __forceinline__ void read_b(i32x8_t (&b)[2], const lds_byte_ptr (&ad)[4], int off) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) b[ks] = join8(*reinterpret_cast<lds_frag_ptr>(ad[ks] + off), *reinterpret_cast<lds_frag_ptr>(ad[ks] + off + 16));
+}
 template <int V>
-__device__ __forceinline__ void mma_quadrant(f32x16_t (&acc)[2], const bf16x8_t (&a)[2][4], const bf16x8_t (&b)[4]) {
+__device__ __forceinline__ void mma_quadrant(f32x16_t (&acc)[2], const bf16x8_t (&a)[2][4], const bf16x8_t (&b)[4],
+                                             const uint32_t (&)[2], uint32_t) {
   if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt][ks], b[ks], acc[mt], 0, 0, 0);
+  if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(0);
+}
+template <int V>
+__device__ __forceinline__ void mma_quadrant(f32x16_t (&acc)[2], const i32x8_t (&a)[2][2], const i32x8_t (&b)[2],
+                                             const uint32_t (&sa)[2], uint32_t sb) {
+  if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      acc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[mt][ks], b[ks], acc[mt], 0, 0, 0, (int)sa[mt], 0, (int)sb);
+  // the MFMAs are side-effect free for the optimiser, which otherwise sinks the last K-tiles' chains below their phase
+  // barriers (and spills the fragments to get there): make the accumulators opaque right here
+  asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
   if constexpr (!(V & 2)) __builtin_amdgcn_s_setprio(0);
 }
 
@@ -93,10 +133,22 @@ __device__ __forceinline__ void stage_tile(const f32x16_t& acc, float* stage, in
 
 // V: schedule variants for A/B runs (bit 0: no explicit lgkmcnt(0) after the phase barrier -- the compiler's own
 // counted waits sit between the MFMAs; bit 1: no s_setprio around the MFMA clusters).
-template <int V>
-__global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restrict__ A, int lda,
-                                                         const bf16_t* __restrict__ Bt, int ldb, int M, int N, int K,
-                                                         int tiles_n, int nwg, GemmEpilogue ep) {
+// F8: the operands are OCP e4m3 bytes with one power-of-two (E8M0) scale per ROW of A and of Bt (sa[M], sb[N], byte 0 of
+// a dword): the same 128-byte LDS rows then hold 128 K-elements, a K-tile is two v_mfma_scale_f32_32x32x64_f8f6f4 steps
+// per 32x32 tile instead of four 32x32x16 bf16 steps (2x the MFMA rate, half the operand bytes per flop), and the
+// hardware applies 2^(sa + sb - 254) to every product.  Operand layout of the scaled MFMA as measured on gfx950
+// (tools/fp8_probe.hip): VGPRs 0-3 of a lane belong to K-block 0 of the 64-wide step, VGPRs 4-7 to K-block 1, the lane
+// halves split each block's 32 elements 16 / 16; the scale of block b of row r is taken from lane r + 32 b.  With one
+// scale per ROW both blocks carry the same exponent, so only the byte-for-byte pairing of the A and B fragments matters:
+// lane half kh simply takes the 32 contiguous bytes [64 ks + 32 kh, +32) of its row (one 8-register LDS load).
+template <int V, bool F8>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict__ Av, int lda,
+                                                         const void* __restrict__ Btv, int ldb, int M, int N, int K,
+                                                         int tiles_n, int nwg, GemmEpilogue ep,
+                                                         const uint32_t* __restrict__ scale_a, const uint32_t* __restrict__ scale_b) {
+  constexpr int ESZ = F8 ? 1 : 2;                 // bytes per operand element
+  const unsigned char* A = reinterpret_cast<const unsigned char*>(Av);
+  const unsigned char* Bt = reinterpret_cast<const unsigned char*>(Btv);
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
 
   const int bid = blockIdx.x;
@@ -117,16 +169,29 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   // Source address = buffer descriptor over the tile's 256-row band + one 32-bit per-lane byte offset (VGPR) + a
   // wave-uniform byte offset (SGPR): no 64-bit per-lane pointers in the loop.
   const int lrow = lane >> 3;
-  const int sw_src = ((w & 1) * 4 + (lrow >> 1)) & 7;
-  const int gk = ((lane & 7) ^ sw_src) * 8;
-  const uint32_t a_lane = (uint32_t)(((w * 8 + lrow) * lda + gk) * 2);
-  const uint32_t b_lane = (uint32_t)((((w >> 2) * 64 + (w & 3) * 8 + lrow) * ldb + gk) * 2);
+  // e4m3: the swizzle moves 32-byte chunk PAIRS only (a lane's fragment = 32 contiguous bytes, pair P at P ^ ((r>>1)&3)),
+  // so that the two halves of a pair keep their order for every row (A and B fragments must pair byte for byte)
+  const int sw_src = F8 ? 2 * (((w & 1) * 4 + (lrow >> 1)) & 3) : ((w & 1) * 4 + (lrow >> 1)) & 7;
+  const int gkb = ((lane & 7) ^ sw_src) * 16;                       // source chunk, bytes
+  const uint32_t a_lane = (uint32_t)((w * 8 + lrow) * lda * ESZ + gkb);
+  const uint32_t b_lane = (uint32_t)(((w >> 2) * 64 + (w & 3) * 8 + lrow) * ldb * ESZ + gkb);
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(A + (size_t)m0 * lda), 0, TM * lda * 2, 0x00020000);
+      const_cast<unsigned char*>(A + (size_t)m0 * lda * ESZ), 0, TM * lda * ESZ, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<bf16_t*>(Bt + (size_t)n0 * ldb), 0, TN * ldb * 2, 0x00020000);
-  const uint32_t a_round = (uint32_t)(128 * lda * 2), a_half = (uint32_t)(64 * lda * 2);
-  const uint32_t b_round = (uint32_t)(128 * ldb * 2), b_half = (uint32_t)(32 * ldb * 2);
+      const_cast<unsigned char*>(Bt + (size_t)n0 * ldb * ESZ), 0, TN * ldb * ESZ, 0x00020000);
+  const uint32_t a_round = (uint32_t)(128 * lda * ESZ), a_half = (uint32_t)(64 * lda * ESZ);
+  const uint32_t b_round = (uint32_t)(128 * ldb * ESZ), b_half = (uint32_t)(32 * ldb * ESZ);
+  // row scales of this lane's fragment rows (F8): A rows m0 + wr*128 + qi*64 + mt*32 + (lane&31), B rows n0 + wc*64 +
+  // qj*32 + (lane&31).  Loaded first (the oldest outstanding loads); their wait is placed behind the DMA prologue.
+  uint32_t sa_[2][2] = {{0u, 0u}, {0u, 0u}}, sb_[2] = {0u, 0u};
+  if constexpr (F8) {
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) sa_[qi][mt] = scale_a[m0 + (tid >> 8) * 128 + qi * 64 + mt * 32 + (lane & 31)];
+#pragma unroll
+    for (int qj = 0; qj < 2; ++qj) sb_[qj] = scale_b[n0 + ((tid >> 6) & 3) * 64 + qj * 32 + (lane & 31)];
+  }
   unsigned char* lds_w = smem + w * 1024;
 
 #define STAGE_A(buf, h, kt)                                                                       \
@@ -149,7 +214,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   lds_byte_ptr a_ad0[4], a_ad1[4], b_ad0[4], b_ad1[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const int ko = (lane & 31) * 128 + (((ks * 2 + kh) ^ fsw) << 4);
+    const int ko = F8 ? (lane & 31) * 128 + ((((ks & 1) * 4 + kh * 2) ^ (2 * (fsw & 3))) << 4)      // ks >= 2 unused
+                      : (lane & 31) * 128 + (((ks * 2 + kh) ^ fsw) << 4);
     a_ad0[ks] = lds0 + wr * 64 * 128 + ko;
     b_ad0[ks] = lds0 + wc * 32 * 128 + ko;
     a_ad1[ks] = a_ad0[ks] + KT_BYTES;
@@ -166,9 +232,9 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.0f;
-  Frags f;
+  typename std::conditional<F8, Frags8, Frags>::type f;
 
-  const int nk = (V & 64) ? 0 : K / TK;   // even, >= 2 (checked by the launcher); V&64: ablation, epilogue only
+  const int nk = (V & 64) ? 0 : K * ESZ / 128;   // K-tiles of 128 operand bytes per row: even, >= 2 (checked by the launcher)
   if constexpr ((V & 64) == 0) {
 
   // ---- prologue: K-tile 0 complete in buffer 0, B0 A0 B1 of K-tile 1 in flight; wave row 1 one barrier behind
@@ -180,6 +246,10 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
   SMD_VMCNT(6);
   SMD_BAR();
   SMD_PIN();
+  if constexpr (F8) {      // the compiler's wait for the scale loads lands here (they are older than every DMA above)
+    asm volatile("" ::"v"(sa_[0][0]), "v"(sa_[0][1]), "v"(sa_[1][0]), "v"(sa_[1][1]), "v"(sb_[0]), "v"(sb_[1]));
+    SMD_PIN();
+  }
 
   // One K-tile from buffer `cur`; the four DMA slots of its phases are given by the caller.
 #define KTILE(cur, S1, S2, S3, S4, WAIT4)                                                         \
@@ -194,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     SMD_BAR();                                                                                    \
     if constexpr (!(V & 1)) SMD_LGKMCNT(0);                                                       \
     SMD_PIN();                                                                                    \
-    mma_quadrant<V>(acc[0][0], f.a, f.b0);                                                           \
+    mma_quadrant<V>(acc[0][0], f.a, f.b0, sa_[0], sb_[0]);                                                           \
     SMD_PIN();                                                                                    \
     SMD_BAR();                                                                                    \
     SMD_PIN();                                                                                    \
@@ -205,7 +275,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     SMD_BAR();                                                                                    \
     if constexpr (!(V & 1)) SMD_LGKMCNT(0);                                                       \
     SMD_PIN();                                                                                    \
-    mma_quadrant<V>(acc[0][1], f.a, f.b1);                                                           \
+    mma_quadrant<V>(acc[0][1], f.a, f.b1, sa_[0], sb_[1]);                                                           \
     SMD_PIN();                                                                                    \
     SMD_BAR();                                                                                    \
     SMD_PIN();                                                                                    \
@@ -216,7 +286,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     SMD_BAR();                                                                                    \
     if constexpr (!(V & 1)) SMD_LGKMCNT(0);                                                       \
     SMD_PIN();                                                                                    \
-    mma_quadrant<V>(acc[1][0], f.a, f.b0);                                                           \
+    mma_quadrant<V>(acc[1][0], f.a, f.b0, sa_[1], sb_[0]);                                                           \
     SMD_PIN();                                                                                    \
     SMD_BAR();                                                                                    \
     SMD_PIN();                                                                                    \
@@ -226,13 +296,13 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const bf16_t* __restric
     SMD_PIN();                                                                                    \
     SMD_BAR();                                                                                    \
     SMD_PIN();                                                                                    \
-    mma_quadrant<V>(acc[1][1], f.a, f.b1);                                                           \
+    mma_quadrant<V>(acc[1][1], f.a, f.b1, sa_[1], sb_[1]);                                                           \
     SMD_PIN();                                                                                    \
     SMD_BAR();                                                                                    \
     SMD_PIN();                                                                                    \
   } while (0)
 
-  if constexpr ((V & 4) != 0) {   // ablation (wrong results): fragments read once
+  if constexpr ((V & 4) != 0 && !F8) {   // ablation (wrong results): fragments read once
     read_b(f.b0, b_ad0, OFF_B0); read_b(f.b1, b_ad0, OFF_B1); read_a(f, a_ad0, OFF_A0);
   }
   int kt = 0;
@@ -310,7 +380,7 @@ int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M
   const int tiles_m = M / TM, tiles_n = N / TN;
   const int nwg = tiles_m * tiles_n;
   SMD_ARG_CHECK(smd_epi::oct_ok(ep), "gemm_nt256: epilogue not supported (alignment / alpha / res_bf16 / accumulate)");
-#define SMD_NT256_LAUNCH(V_) hipLaunchKernelGGL(gemm_nt256_kernel<V_>, dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep)
+#define SMD_NT256_LAUNCH(V_) hipLaunchKernelGGL((gemm_nt256_kernel<V_, false>), dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep, nullptr, nullptr)
   // schedule variants 1..3 compute the same result (A/B runs); the ABLATION variants (bits 4, 8, 32, 64: parts of the
   // kernel removed, wrong results by construction) exist only in a -DSMD_ABLATIONS build (tools/kbench.py --gemm-ab)
   switch (smd_tuning_get("gemm_nt256_variant")) {
@@ -331,6 +401,22 @@ int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M
       return -1;
   }
 #undef SMD_NT256_LAUNCH
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+// e4m3 operands with per-row E8M0 scales (see the kernel comment): C = (2^sa[m] A8[m,:]) . (2^sb[n] Bt8[n,:]) + epilogue
+int launch_gemm_nt256_fp8(const unsigned char* A8, int lda, const uint32_t* scale_a, const unsigned char* Bt8, int ldb,
+                          const uint32_t* scale_b, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st) {
+  SMD_ARG_CHECK(A8 && Bt8 && scale_a && scale_b, "gemm_nt256_fp8: null operand");
+  SMD_ARG_CHECK(M % TM == 0 && N % TN == 0 && K % 256 == 0 && K >= 256,
+                "gemm_nt256_fp8: M=%d N=%d must be multiples of 256 and K=%d a multiple of 256", M, N, K);
+  SMD_ARG_CHECK(lda % 16 == 0 && ldb % 16 == 0 && lda >= K && ldb >= K, "gemm_nt256_fp8: lda=%d ldb=%d must be >= K and multiples of 16", lda, ldb);
+  SMD_ARG_CHECK(smd_epi::oct_ok(ep), "gemm_nt256_fp8: epilogue not supported (alignment / alpha / res_bf16 / accumulate)");
+  SMD_ARG_CHECK(ep.out_f32 || ep.out_bf16 || ep.pre_bf16, "gemm_nt256_fp8: no output");
+  const int tiles_n = N / TN, nwg = (M / TM) * tiles_n;
+  hipLaunchKernelGGL((gemm_nt256_kernel<0, true>), dim3(nwg), dim3(512), 0, st, A8, lda, Bt8, ldb, M, N, K, tiles_n, nwg, ep, scale_a,
+                     scale_b);
   SMD_LAUNCH_CHECK();
   return 0;
 }

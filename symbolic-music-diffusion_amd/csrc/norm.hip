@@ -147,7 +147,9 @@ template <int D, bool XBF> struct WideRow {
 // shift) from the L2 for every row -- 4x the bytes of the row itself.  Here a workgroup of 8 waves owns one row group
 // (a sample's rows with per-sample FiLM, else 32 rows), keeps the parameters in LDS and walks the group's rows
 // (SGPR row bases, all of a row's loads issued up front).  FS: FiLM + swish (ResBlock norms) or neither.
-template <int D, bool XBF, bool FS, int NW>
+// F8: also (or only) write the row as e4m3 with a per-row E8M0 scale (the A operand of the e4m3 GEMM); the row's outputs
+// then wait in registers for the row maximum.
+template <int D, bool XBF, bool FS, int NW, bool F8 = false>
 __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, int group_rows) {
   typedef RowLayout<D> L;
   constexpr int NV = L::NV;
@@ -187,6 +189,8 @@ __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, i
     const float mean = s * (1.0f / D);
     const float rstd = rsqrtf(sq * (1.0f / D) - mean * mean + LN_EPS);
     bf16_t* orow = a.out + (size_t)row * D;
+    float yk[F8 ? NV : 1][4];
+    float amax = 0.f;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int c = k * 256 + lane * 4;
@@ -203,11 +207,26 @@ __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = swishf_(ss[e] * y[e] + hh[e]);
       }
-      bf16x4_t t;
+      if (!F8 || a.out) {
+        bf16x4_t t;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) t[e] = f2bf(y[e]);
-      *reinterpret_cast<bf16x4_t*>(orow + (l4 + k * 256)) = t;
+        for (int e = 0; e < 4; ++e) t[e] = f2bf(y[e]);
+        *reinterpret_cast<bf16x4_t*>(orow + (l4 + k * 256)) = t;
+      }
+      if constexpr (F8) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { yk[k][e] = y[e]; amax = fmaxf(amax, fabsf(y[e])); }
+      }
       __builtin_amdgcn_sched_barrier(0);      // keep the LDS parameter reads of later chunks from being hoisted (VGPRs)
+    }
+    if constexpr (F8) {
+      amax = wave_max(amax);
+      const int ex = e4m3_row_exponent(amax);
+      unsigned char* o8 = a.out_f8 + (size_t)row * D;
+#pragma unroll
+      for (int k = 0; k < NV; ++k)
+        *reinterpret_cast<unsigned*>(o8 + (l4 + k * 256)) = pack4_e4m3(yk[k][0], yk[k][1], yk[k][2], yk[k][3], ex);
+      if (lane == 0) a.out_scale[row] = (unsigned)(ex + 127);
     }
   }
 }
@@ -838,7 +857,9 @@ size_t ln_bwd_partial_elems(int rows, int D) {
 
 static int check_ln(const LnArgs& a, bool need_out) {
   SMD_ARG_CHECK((a.x != nullptr) != (a.x_bf16 != nullptr), "layernorm: exactly one of x / x_bf16");
-  SMD_ARG_CHECK(a.gamma && a.beta && (a.out || !need_out), "layernorm: null gamma/beta/out");
+  SMD_ARG_CHECK(a.gamma && a.beta && (a.out || a.out_f8 || !need_out), "layernorm: null gamma/beta/out");
+  SMD_ARG_CHECK(!a.out_f8 || (a.out_scale && (a.D == 1024 || a.D == 2048) && ((a.film_scale != nullptr) == (a.swish != 0))),
+                "layernorm: e4m3 output needs out_scale, D in {1024, 2048} and FiLM+swish or neither");
   SMD_ARG_CHECK(a.rows > 0, "layernorm: rows=%d", a.rows);
   SMD_ARG_CHECK((a.film_scale != nullptr) == (a.film_shift != nullptr), "layernorm: scale/shift must come together");
   if (a.film_scale) {
@@ -864,11 +885,13 @@ template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
   if constexpr (D == 1024 || D == 2048) {
     const bool fs = a.film_scale && a.swish, plain = !a.film_scale && !a.swish;
     const int gr = (a.film_scale && !a.t_ptr) ? a.rows_per_sample : 32;
-    if (smd_tuning_get("ln_fwd_wide") && (fs || plain) && gr >= 8) {
+    if ((smd_tuning_get("ln_fwd_wide") || a.out_f8) && (fs || plain) && gr >= 8) {
       const int ng = (a.rows + gr - 1) / gr;
 #define SMD_FW(XB, FS_)                                                                                               \
   do {                                                                                                               \
-    if (smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16>), dim3(ng), dim3(1024), 0, st, a, gr); \
+    if (a.out_f8 && smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16, true>), dim3(ng), dim3(1024), 0, st, a, gr); \
+    else if (a.out_f8) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 8, true>), dim3(ng), dim3(512), 0, st, a, gr);       \
+    else if (smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16>), dim3(ng), dim3(1024), 0, st, a, gr); \
     else hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 8>), dim3(ng), dim3(512), 0, st, a, gr);            \
   } while (0)
       if (a.x_bf16) { if (fs) SMD_FW(true, true); else SMD_FW(true, false); }
@@ -986,5 +1009,40 @@ int launch_ln_bwd_reduce_batched(const LnReduceEntry* entries, int n, hipStream_
     hipLaunchKernelGGL(ln_bwd_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, t);
     SMD_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+// rows of a bf16 matrix -> e4m3 + per-row E8M0 scale: one wave per row, 8 elements per lane and pass
+namespace {
+__global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const bf16_t* __restrict__ in, int ld, int rows, int K,
+                                                                 unsigned char* __restrict__ out8, uint32_t* __restrict__ scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* src = in + (size_t)row * ld;
+  float amax = 0.f;
+  for (int c = lane * 8; c < K; c += 512) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(bf2f(v[e])));
+  }
+  amax = wave_max(amax);
+  const int ex = e4m3_row_exponent(amax);
+  unsigned char* dst = out8 + (size_t)row * K;
+  for (int c = lane * 8; c < K; c += 512) {
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src + c);
+    uint2 o;
+    o.x = pack4_e4m3(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3]), ex);
+    o.y = pack4_e4m3(bf2f(v[4]), bf2f(v[5]), bf2f(v[6]), bf2f(v[7]), ex);
+    *reinterpret_cast<uint2*>(dst + c) = o;
+  }
+  if (lane == 0) scale[row] = (unsigned)(ex + 127);
+}
+}  // namespace
+
+int launch_quantize_rows_e4m3(const bf16_t* in, int ld, int rows, int K, unsigned char* out8, uint32_t* scale, hipStream_t st) {
+  SMD_ARG_CHECK(in && out8 && scale && rows > 0 && K > 0 && K % 8 == 0 && ld >= K && ld % 8 == 0, "quantize_rows_e4m3: bad arguments");
+  hipLaunchKernelGGL(quantize_rows_e4m3_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, in, ld, rows, K, out8, scale);
+  SMD_LAUNCH_CHECK();
   return 0;
 }

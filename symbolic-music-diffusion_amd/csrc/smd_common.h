@@ -73,6 +73,22 @@ __device__ __forceinline__ float gelu_gradf_(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 
+// ---- OCP e4m3 with a per-row power-of-two scale: e = floor(log2(amax)) - 8 puts amax * 2^-e into [256, 512), clamped to
+// the format's 448; the E8M0 byte the scaled MFMA takes is e + 127
+__device__ __forceinline__ int e4m3_row_exponent(float amax) {
+  if (!(amax > 0.0f)) return 0;
+  const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFF) - 127 - 8;
+  return e < -126 ? -126 : e;
+}
+__device__ __forceinline__ unsigned pack4_e4m3(float a, float b, float c, float d, int e) {
+  const float lim = 448.0f;
+  a = fminf(fmaxf(ldexpf(a, -e), -lim), lim); b = fminf(fmaxf(ldexpf(b, -e), -lim), lim);
+  c = fminf(fmaxf(ldexpf(c, -e), -lim), lim); d = fminf(fmaxf(ldexpf(d, -e), -lim), lim);
+  int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+  return (unsigned)v;
+}
+
 // ---- wave64 reductions (DPP/bpermute via __shfl_xor) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

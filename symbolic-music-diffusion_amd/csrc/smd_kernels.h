@@ -40,6 +40,12 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
 bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep);
 int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
                       const GemmEpilogue& ep, hipStream_t st);
+// the same tile and pipeline on OCP e4m3 operands with one E8M0 (power-of-two) scale per row of A and of Bt (dword
+// arrays, byte 0), v_mfma_scale_f32_32x32x64_f8f6f4: M, N % 256 == 0, K % 256 == 0, lda / ldb in elements (= bytes)
+int launch_gemm_nt256_fp8(const unsigned char* A8, int lda, const uint32_t* scale_a, const unsigned char* Bt8, int ldb,
+                          const uint32_t* scale_b, int M, int N, int K, const GemmEpilogue& ep, hipStream_t st);
+// rows of a bf16 matrix -> e4m3 bytes + one E8M0 scale per row (weights of the e4m3 GEMM path): K % 512 == 0
+int launch_quantize_rows_e4m3(const bf16_t* in, int ld, int rows, int K, unsigned char* out8, uint32_t* scale, hipStream_t st);
 // process-wide kernel-selection knobs (benchmark A/B; defaults are the fast paths). Keys: "gemm_nt256", "gemm_nt256_variant", "gemm_tn256".
 int smd_tuning_set(const char* key, int value);
 int smd_tuning_get(const char* key);
@@ -96,6 +102,10 @@ struct LnArgs {
   const int* t_ptr = nullptr;
   int swish = 0;
   bf16_t* out = nullptr;             // [rows][D]
+  // e4m3 copy of the output with one power-of-two scale per row (D = 1024 / 2048 row-group kernels only): out_f8
+  // [rows][D] bytes = e4m3(y * 2^-e), out_scale [rows] dwords = E8M0 byte e + 127; `out` may then be null
+  unsigned char* out_f8 = nullptr;
+  uint32_t* out_scale = nullptr;
 };
 int launch_layernorm_fwd(const LnArgs& a, hipStream_t st);
 

@@ -34,6 +34,7 @@ class NetConfig:
     num_mlp_layers: int = 2
     mlp_dims: int = 2048
     num_timesteps: int = 1000
+    dtype: str = "bf16"          # "fp8": e4m3 DenseResBlock forward GEMMs (--dtype=fp8, BASELINE config 5)
 
     @property
     def sample_shape(self) -> Tuple[int, ...]:
@@ -69,6 +70,10 @@ class Engine:
         h = C.c_void_p()
         _lib.check(self.L.smd_engine_create(C.byref(d), C.byref(h)), "smd_engine_create")
         self.h = h
+        if cfg.dtype not in ("bf16", "fp8"):
+            raise ValueError(f"dtype must be 'bf16' or 'fp8', got {cfg.dtype!r}")
+        if cfg.dtype == "fp8":
+            _lib.check(self.L.smd_engine_set_option(h, b"fp8", 1), "set_option fp8")
         self.S = d.seq_len
         self.C = cfg.data_channels
         self.n_params = int(self.L.smd_engine_param_count(h))
@@ -86,6 +91,9 @@ class Engine:
                 self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
                 self.wpack = torch.zeros(int(self.L.smd_engine_wpack_elems(h)), dtype=torch.int16, device=self.device)
             _lib.check(self.L.smd_engine_bind_params(h, _ptr(self.params), _ptr(self.wpack)), "bind_params")
+        # engines sharing one operand pack: a weight refresh through any handle invalidates every handle's e4m3 copies
+        self._wstate = share_params_with._wstate if share_params_with is not None else {"ver": 0}
+        self._wseen = -1
         self.grads = self.m = self.v = self.ema = None
         self.step_counter = None
         self.metrics = None
@@ -147,6 +155,14 @@ class Engine:
     def refresh_weights(self) -> None:
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_refresh_weights(self.h, _stream()), "refresh_weights")
+        self._wstate["ver"] += 1
+        self._wseen = self._wstate["ver"]
+
+    def _sync_fp8_weights(self) -> None:
+        """fp8 mode: tell this handle when the shared bf16 operand pack was refreshed through another handle."""
+        if self.cfg.dtype == "fp8" and self._wseen != self._wstate["ver"]:
+            _lib.check(self.L.smd_engine_set_option(self.h, b"w8_dirty", 1), "set_option w8_dirty")
+            self._wseen = self._wstate["ver"]
 
     def set_option(self, key: str, value: int) -> None:
         _lib.check(self.L.smd_engine_set_option(self.h, key.encode(), int(value)), "set_option")
@@ -206,6 +222,7 @@ class Engine:
         if s.numel() != B:
             raise ValueError(f"noise level has {s.numel()} entries for batch {B}")
         self.bind(B, training=False)
+        self._sync_fp8_weights()
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_forward(self.h, _ptr(x), _ptr(s), _ptr(out), _stream()), "forward")
@@ -218,6 +235,7 @@ class Engine:
         B = x0.shape[0] if x0 is not None else self.batch
         gb = B if global_batch is None else global_batch
         inv = 1.0 / (gb * float(np.prod(self.cfg.sample_shape)))
+        self._sync_fp8_weights()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_loss_backward(self.h, _ptr(x0), _ptr(labels), _ptr(eps), seed & 0xFFFFFFFF,
                                                        (seed >> 32) & 0xFFFFFFFF, sample_offset, inv, stage,
@@ -229,6 +247,8 @@ class Engine:
         h = _lib.TrainHyper(lr0, lr_gamma, lr_interval, beta1, beta2, eps, grad_clip, mu, grad_scale)
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_optimizer_step(self.h, C.byref(h), _stream()), "optimizer_step")
+        self._wstate["ver"] += 1            # the step re-casts the operand pack (this handle re-quantises itself)
+        self._wseen = self._wstate["ver"]
 
     def _borrow(self, ptr: int, shape) -> torch.Tensor:
         """View of an engine-internal fp32 buffer inside our workspace tensor."""
@@ -261,6 +281,7 @@ class Engine:
             _lib.check(self.L.smd_engine_load_state(self.h, _ptr(x), _stream()), "load_state")
 
     def sample_step(self, io: "_lib.SampleIO") -> None:
+        self._sync_fp8_weights()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_sample_step(self.h, C.byref(io), _stream()), "sample_step")
 

@@ -229,7 +229,8 @@ SAMPLE_FLAGS: List[FlagDef] = [
 
 # engine-only additions (no collision with the reference surface)
 ENGINE_FLAGS: List[FlagDef] = [
-    _D("dtype", "enum", "bf16", "GEMM operand precision of the HIP path.", ("bf16",)),
+    _D("dtype", "enum", "bf16", "GEMM operand precision of the HIP path: bf16, or fp8 = OCP e4m3 operands with per-row "
+       "E8M0 scales for the DenseResBlock forward GEMMs (BASELINE config 5), bf16 elsewhere.", ("bf16", "fp8")),
     _D("synthetic", "bool", False, "Use synthetic latents clip(0.25*N(0,1),-1,1) instead of --dataset."),
     _D("synthetic_examples", "int", 4096, "Synthetic examples per epoch."),
     _D("sample_ema", "bool", False, "sample_ncsn: sample from the EMA weights (reference uses raw weights)."),

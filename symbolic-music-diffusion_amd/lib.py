@@ -77,6 +77,11 @@ _SIGS = {
     "smd_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "smd_gemm_bf16_nt": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
+    "smd_quantize_rows_e4m3": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
+    "smd_gemm_e4m3_nt": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void,
+                                   C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
+    "smd_layernorm_fwd_e4m3": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int,
+                                         c_void, c_void, c_void, c_void]),
     "smd_mlp_block_fwd": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, c_void,
                                     c_void, c_void, c_void]),
     "smd_mlp_block_fwd_hs": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, C.c_int, c_void, c_void]),

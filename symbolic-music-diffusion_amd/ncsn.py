@@ -110,7 +110,7 @@ class Model:
 
 
 def config_from_kwargs(architecture: str, input_shape: Sequence[int], model_kwargs: dict,
-                       num_timesteps: int = 1000) -> NetConfig:
+                       num_timesteps: int = 1000, dtype: str = "bf16") -> NetConfig:
     if architecture not in ARCH_IDS:
         raise ValueError(f"Unsupported architecture {architecture!r} (HIP engine: {sorted(ARCH_IDS)})")
     input_shape = tuple(int(v) for v in input_shape)
@@ -126,15 +126,16 @@ def config_from_kwargs(architecture: str, input_shape: Sequence[int], model_kwar
                      num_layers=int(model_kwargs.get("num_layers", 6)),
                      num_heads=int(model_kwargs.get("num_heads", 8)),
                      num_mlp_layers=int(model_kwargs.get("num_mlp_layers", 2)),
-                     mlp_dims=int(model_kwargs.get("mlp_dims", 2048)), num_timesteps=num_timesteps)
+                     mlp_dims=int(model_kwargs.get("mlp_dims", 2048)), num_timesteps=num_timesteps, dtype=dtype)
 
 
 def create_model(rng: PRNGKey, input_shape, model_kwargs, batch_size=32, verbose=False, *,
-                 architecture: str = "TransformerDDPM", num_timesteps: int = 1000, device: str = "cuda:0") -> Model:
+                 architecture: str = "TransformerDDPM", num_timesteps: int = 1000, device: str = "cuda:0",
+                 dtype: str = "bf16") -> Model:
     """train_ncsn.py:193-203.  ``architecture`` replaces the FLAGS.architecture global; DenseDDPM
     accepts-and-ignores num_heads / num_mlp_layers like the reference's kwargs."""
     del batch_size
-    cfg = config_from_kwargs(architecture, input_shape, model_kwargs, num_timesteps)
+    cfg = config_from_kwargs(architecture, input_shape, model_kwargs, num_timesteps, dtype)
     model = Model(cfg, device, seed=rng.seed & 0x7FFFFFFF)
     if verbose:
         from .train_utils import report_model

@@ -76,7 +76,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                         num_mlp_layers=FLAGS.num_mlp_layers, mlp_dims=FLAGS.mlp_dims)
     dev = f"cuda:{torch.cuda.current_device()}"
     model = ncsn.create_model(model_rng, input_shape, model_kwargs, FLAGS.batch_size, verbose=verbose and rank == 0,
-                              architecture=FLAGS.architecture, num_timesteps=len(sigmas), device=dev)
+                              architecture=FLAGS.architecture, num_timesteps=len(sigmas), device=dev, dtype=FLAGS.dtype)
     optimizer = create_optimizer(model, FLAGS.learning_rate, ema=FLAGS.ema)       # :332
     comm = GradComm() if world > 1 else None
     if comm is not None:
