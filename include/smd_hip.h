@@ -88,6 +88,10 @@ int smd_engine_forward(smd_engine* e, const float* x, const float* noise_level, 
 int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labels, const float* eps_in,
                              uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset,
                              float inv_global_count, int stage, void* stream);
+/* continuous_noise=False (utils/losses.py:272-286; option "label_min" = 0): labels are drawn in [0, T) and label 0 takes
+ * a real uniform used_alpha in [alphas_prod[T], 1).  used_alphas ([B] device floats, or NULL) replaces the label -> alpha
+ * lookup of the following smd_engine_loss_backward calls (parity mode: the reference's own jax.random.uniform draws). */
+int smd_engine_set_used_alphas(smd_engine* e, const float* used_alphas);
 const float* smd_engine_loss_per_sample(const smd_engine* e);   /* [B] device pointer */
 const float* smd_engine_pred(const smd_engine* e);              /* [B*S][C] device pointer */
 
@@ -235,6 +239,24 @@ int smd_attention_bwd(const smd_bf16* qkv, const smd_bf16* dout, smd_bf16* dqkv,
                       void* stream);
 /* NoiseEncoding.apply, models/ncsn.py:28-41 */
 int smd_noise_embed(const float* noise_level, int n, int channels, smd_bf16* out, int ld_out, void* stream);
+/* The loss-side and optimiser kernels without an engine handle (the engine calls the same launchers).
+ * smd_q_sample: utils/losses.py:271-296.  x0 [B][S][C] fp32 -> xt_bf16 [B*S][Cp] (the columns >= C are not written),
+ *   eps_out [B][S][C], noise_level_out [B] = sqrt(used_alpha).  labels NULL -> Philox labels in
+ *   [label_min, label_min + T) keyed by (seed, b + sample_offset, *step_ptr); used_alphas NULL -> alphas_prod_ext[label - 1]
+ *   (label 0: a uniform draw in [alphas_prod_ext[T], 1)); eps_in NULL -> Philox normals.  S*C need not be a multiple of 4.
+ * smd_mse_fwd_bwd: :304-305 and d(mean loss)/d pred: loss_per_sample [B], dpred_bf16 [B*S][Cp] = 2 (pred - eps) *
+ *   inv_global_count.
+ * smd_adam_clip_ema: train_ncsn.py:284-287,340-342,364-365 on flat fp32 buffers of n elements: gradient norm -> clip ->
+ *   Adam with the stepped LR evaluated from *step_ptr (incremented by the kernel) -> EMA (ema may be NULL).
+ *   norm_partial: >= 1024 floats of scratch; metrics_out [4] = norm before clip, after clip, lr, step. */
+int smd_q_sample(const float* x0, int B, int S, int C, int Cp, int T, const float* alphas_prod_ext, const int32_t* labels,
+                 int label_min, const float* used_alphas, const float* eps_in, uint32_t seed_lo, uint32_t seed_hi,
+                 const uint32_t* step_ptr, uint32_t sample_offset, smd_bf16* xt_bf16, float* eps_out,
+                 float* noise_level_out, void* stream);
+int smd_mse_fwd_bwd(const float* pred, const float* eps, int B, int S, int C, int Cp, float inv_global_count,
+                    float* loss_per_sample, smd_bf16* dpred_bf16, void* stream);
+int smd_adam_clip_ema(float* params, const float* grads, float* m, float* v, float* ema, int64_t n,
+                      const smd_train_hyper* h, uint32_t* step_ptr, float* norm_partial, float* metrics_out, void* stream);
 /* Philox4x32-10 normals: out[b][e], counter (e/4, b + sample_offset, stream_id, 0) */
 int smd_rng_normal(float* out, int B, int per_sample, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream_id,
                    uint32_t sample_offset, void* stream);

@@ -338,18 +338,27 @@ def reduce_fn(x, mode):
     raise ValueError("Unsupported reduction option.")
 
 
-def used_alphas_from_labels(betas: np.ndarray, labels: np.ndarray) -> np.ndarray:
+def used_alphas_from_labels(betas: np.ndarray, labels: np.ndarray, u01: Optional[np.ndarray] = None) -> np.ndarray:
     """utils/losses.py:277-286 with the jax-0.2.8 uniform quirk: minval=alphas_prod'[l-1] >
-    maxval=alphas_prod'[l] so uniform(...) returns minval exactly (ORACLE_ASSUMPTIONS)."""
-    ap = np.concatenate([np.ones((1,), np.float32), alphas_cumprod(betas)])
-    return ap[labels - 1]
+    maxval=alphas_prod'[l] so uniform(...) returns minval exactly (ORACLE_ASSUMPTIONS).  Label 0 (continuous_noise=False
+    only) indexes alphas_prod'[-1] = alphas_prod[T] < alphas_prod'[0] = 1: a real draw max(lo, u01 * (hi - lo) + lo) in
+    float32, ``u01`` being the [0, 1) floats of jax.random.uniform (required when a label is 0)."""
+    ap = np.concatenate([np.ones((1,), np.float32), alphas_cumprod(betas)]).astype(np.float32)
+    labels = np.asarray(labels)
+    lo, hi = ap[labels - 1], ap[labels % len(ap)]
+    if u01 is None:
+        if (labels == 0).any():
+            raise ValueError("label 0 needs its uniform draw (u01)")
+        return lo
+    u01 = np.asarray(u01, dtype=np.float32)
+    return np.maximum(lo, (u01 * (hi - lo)).astype(np.float32) + lo).astype(np.float32)
 
 
-def diffusion_loss(batch, model, betas, labels, eps, reduction="mean"):
-    """utils/losses.py:250-308 with the random draws (labels :272-275, eps :294) passed in
-    explicitly; continuous_noise=True branch (labels in [1, T]).  Conditions on sqrt(alpha)."""
+def diffusion_loss(batch, model, betas, labels, eps, reduction="mean", u01=None):
+    """utils/losses.py:250-308 with the random draws (labels :272-275, eps :294, and for continuous_noise=False the
+    uniform floats of :283-286) passed in explicitly.  Conditions on sqrt(alpha)."""
     B = batch.shape[0]
-    a = torch.from_numpy(used_alphas_from_labels(betas, labels)).to(batch.dtype)
+    a = torch.from_numpy(used_alphas_from_labels(betas, labels, u01)).to(batch.dtype)
     a = a.reshape(B, *([1] * (batch.dim() - 1)))
     perturbed = torch.sqrt(a) * batch + torch.sqrt(1 - a) * eps          # :295-296
     pred = model(perturbed, torch.sqrt(a))                                # :299-300
@@ -721,6 +730,13 @@ def jax_diffusion_loss_draws(rng, batch_shape, T: int, continuous_noise: bool = 
     labels = jax_randint(label_rng, B, int(continuous_noise), T + int(continuous_noise))
     eps = jax_normal(sample_rng, int(np.prod(batch_shape))).reshape(batch_shape)
     return labels, eps
+
+
+def jax_diffusion_loss_u01(rng, B: int) -> np.ndarray:
+    """[0, 1) floats behind the uniform of utils/losses.py:282-286: noise_rng = split(first output of split(rng, 3))[1]."""
+    first, _label_rng, _sample_rng = jax_split(rng, 3)
+    _rng, noise_rng = jax_split(first)
+    return jax_uniform(noise_rng, B, 0.0, 1.0)
 
 
 def jax_sampler_keys(ld_rng, T: int):

@@ -179,7 +179,8 @@ def main(argv):
 
     if rank == 0 and FLAGS.flush:                                           # :452-471
         log_dir = FLAGS.sampling_dir
-        inv = lambda b, mn, mx: data.inverse_data_transform(b, FLAGS.normalize, None, mn, mx, slice_idx, dim_weights)
+        pca = data.load(os.path.expanduser(FLAGS.pca_ckpt)) if FLAGS.pca_ckpt else None       # :380-381
+        inv = lambda b, mn, mx: data.inverse_data_transform(b, FLAGS.normalize, pca, mn, mx, slice_idx, dim_weights)
         if not FLAGS.interpolate:
             data.save(inv(collection, tmin, tmax), os.path.join(log_dir, "ncsn/collection.pkl"))
         data.save(inv(real, emin, emax), os.path.join(log_dir, "ncsn/real.pkl"))

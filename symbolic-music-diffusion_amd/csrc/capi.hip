@@ -87,6 +87,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
+  if (std::string(key) == "label_min") { e->impl.label_min = value ? 1 : 0; return 0; }
   if (std::string(key) == "mlp_hs") { e->impl.mlp_hs = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
   if (std::string(key) == "w8_dirty") { e->impl.mark_w8_dirty(); return 0; }   // the bf16 operand pack changed under another handle
@@ -117,6 +118,11 @@ int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labe
                              int stage, void* stream) {
   NEED(e);
   return e->impl.loss_backward(x0, labels, eps_in, seed_lo, seed_hi, sample_offset, inv_global_count, stage, S(stream));
+}
+int smd_engine_set_used_alphas(smd_engine* e, const float* used_alphas) {
+  NEED(e);
+  e->impl.set_used_alphas(used_alphas);
+  return 0;
 }
 const float* smd_engine_loss_per_sample(const smd_engine* e) { return e ? e->impl.loss_per_sample() : nullptr; }
 const float* smd_engine_pred(const smd_engine* e) { return e ? e->impl.pred() : nullptr; }
@@ -282,6 +288,32 @@ int smd_attention_bwd(const smd_bf16* qkv, const smd_bf16* dout, smd_bf16* dqkv,
 }
 int smd_noise_embed(const float* s, int n, int channels, smd_bf16* out, int ld_out, void* stream) {
   return launch_noise_embed(s, n, channels, B(out), ld_out, S(stream));
+}
+int smd_q_sample(const float* x0, int Bn, int Sn, int C, int Cp, int T, const float* alphas_prod_ext, const int32_t* labels,
+                 int label_min, const float* used_alphas, const float* eps_in, uint32_t seed_lo, uint32_t seed_hi,
+                 const uint32_t* step_ptr, uint32_t sample_offset, smd_bf16* xt_bf16, float* eps_out, float* noise_level_out,
+                 void* stream) {
+  QSampleArgs q;
+  q.x0 = x0; q.B = Bn; q.S = Sn; q.C = C; q.Cp = Cp; q.T = T; q.alphas_prod_ext = alphas_prod_ext;
+  q.labels = labels; q.label_min = label_min; q.alpha_in = used_alphas; q.eps_in = eps_in;
+  q.key = RngKey{seed_lo, seed_hi}; q.step_ptr = step_ptr; q.sample_offset = sample_offset;
+  q.xt_bf16 = B(xt_bf16); q.eps_out = eps_out; q.s_out = noise_level_out;
+  return launch_q_sample(q, S(stream));
+}
+int smd_mse_fwd_bwd(const float* pred, const float* eps, int Bn, int Sn, int C, int Cp, float inv_global_count,
+                    float* loss_per_sample, smd_bf16* dpred_bf16, void* stream) {
+  return launch_mse_loss_grad(pred, eps, Bn, Sn, C, Cp, inv_global_count, loss_per_sample, B(dpred_bf16), S(stream));
+}
+int smd_adam_clip_ema(float* params, const float* grads, float* m, float* v, float* ema, int64_t n, const smd_train_hyper* h,
+                      uint32_t* step_ptr, float* norm_partial, float* metrics_out, void* stream) {
+  SMD_ARG_CHECK(h && n > 0, "adam_clip_ema: bad arguments");
+  AdamArgs a;
+  a.params = params; a.grads = grads; a.m = m; a.v = v; a.ema = ema; a.n = (size_t)n;
+  a.lr0 = h->lr0; a.lr_gamma = h->lr_gamma; a.lr_interval = h->lr_interval; a.beta1 = h->beta1; a.beta2 = h->beta2;
+  a.eps = h->eps; a.grad_clip = h->grad_clip; a.mu = h->mu; a.grad_scale = h->grad_scale;
+  a.step_ptr = step_ptr; a.norm_partial = norm_partial; a.metrics_out = metrics_out;
+  int rc = launch_grad_sumsq(a, S(stream));
+  return rc ? rc : launch_adam_clip_ema(a, S(stream));
 }
 int smd_rng_normal(float* out, int Bn, int per_sample, uint32_t lo, uint32_t hi, uint32_t stream_id, uint32_t off, void* stream) {
   return launch_fill_normal(out, Bn, per_sample, RngKey{lo, hi}, stream_id, off, S(stream));

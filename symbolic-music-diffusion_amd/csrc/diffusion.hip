@@ -31,6 +31,9 @@ __global__ __launch_bounds__(256) void noise_embed_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ q-sample
+// VEC4: S*C is a multiple of 4 (16-byte loads / stores).  Otherwise (DenseDDPM on sliced latents: C = 42, 146 ...)
+// the same groups of four Philox normals are used, moved element by element and cut at the end of the sample.
+template <bool VEC4>
 __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
   const int SC = a.S * a.C;
   const int g = blockIdx.x * 256 + threadIdx.x;
@@ -39,30 +42,62 @@ __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
   if (e0 >= SC) return;
   const uint32_t bglob = (uint32_t)b + a.sample_offset;
   const uint32_t step = a.step_ptr ? *a.step_ptr : 0u;
+  const uint4 r = philox4x32_10(make_uint4(0u, bglob, SMD_STREAM_LABEL, step), a.key.seed_lo, a.key.seed_hi);
   int label;
   if (a.labels) {
-    label = a.labels[b];
+    label = min(max(a.labels[b], 0), a.T);
   } else {
-    const uint4 r = philox4x32_10(make_uint4(0u, bglob, SMD_STREAM_LABEL, step), a.key.seed_lo, a.key.seed_hi);
-    label = 1 + (int)(r.x % (uint32_t)a.T);          // randint[1, T+1), utils/losses.py:272-275
+    // randint[1, T+1) (continuous_noise) or randint[0, T) (label_min = 0), utils/losses.py:272-275
+    label = a.label_min + (int)(r.x % (uint32_t)a.T);
   }
-  // jax-0.2.8 uniform(minval=ap[l-1], maxval=ap[l]) degenerates to minval
-  const float alpha = a.alphas_prod_ext[label - 1];
+  float alpha;
+  if (a.alpha_in) {
+    alpha = a.alpha_in[b];
+  } else if (label > 0) {
+    // jax-0.2.8 uniform(minval=ap[l-1], maxval=ap[l]) degenerates to minval
+    alpha = a.alphas_prod_ext[label - 1];
+  } else {
+    // label 0 (only with continuous_noise=False): alphas_prod'[-1] = ap[T] < alphas_prod'[0] = 1, a real uniform draw
+    const float lo = a.alphas_prod_ext[a.T];
+    const float u = __uint_as_float((r.y >> 9) | 0x3F800000u) - 1.0f;
+    alpha = fmaxf(lo, u * (1.0f - lo) + lo);
+  }
   const float sa = sqrtf(alpha), sb = sqrtf(1.0f - alpha);
   const size_t base = (size_t)b * SC + e0;
   float4 eps;
-  if (a.eps_in) eps = *reinterpret_cast<const float4*>(a.eps_in + base);
-  else eps = philox_normal4((uint32_t)g, bglob, SMD_STREAM_EPS, step, a.key.seed_lo, a.key.seed_hi);
-  const float4 x0 = *reinterpret_cast<const float4*>(a.x0 + base);
+  if (a.eps_in) {
+    if constexpr (VEC4) {
+      eps = *reinterpret_cast<const float4*>(a.eps_in + base);
+    } else {
+      eps.x = a.eps_in[base];
+      eps.y = e0 + 1 < SC ? a.eps_in[base + 1] : 0.f;
+      eps.z = e0 + 2 < SC ? a.eps_in[base + 2] : 0.f;
+      eps.w = e0 + 3 < SC ? a.eps_in[base + 3] : 0.f;
+    }
+  } else {
+    eps = philox_normal4((uint32_t)g, bglob, SMD_STREAM_EPS, step, a.key.seed_lo, a.key.seed_hi);
+  }
+  float4 x0;
+  if constexpr (VEC4) {
+    x0 = *reinterpret_cast<const float4*>(a.x0 + base);
+  } else {
+    x0.x = a.x0[base];
+    x0.y = e0 + 1 < SC ? a.x0[base + 1] : 0.f;
+    x0.z = e0 + 2 < SC ? a.x0[base + 2] : 0.f;
+    x0.w = e0 + 3 < SC ? a.x0[base + 3] : 0.f;
+  }
   const float xt[4] = {sa * x0.x + sb * eps.x, sa * x0.y + sb * eps.y, sa * x0.z + sb * eps.z,
                        sa * x0.w + sb * eps.w};
+  const float ev[4] = {eps.x, eps.y, eps.z, eps.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int e = e0 + i;
+    if (!VEC4 && e >= SC) break;
     const int srow = e / a.C, c = e - srow * a.C;
     a.xt_bf16[((size_t)b * a.S + srow) * a.Cp + c] = f2bf(xt[i]);
+    if constexpr (!VEC4) a.eps_out[base + i] = ev[i];
   }
-  *reinterpret_cast<float4*>(a.eps_out + base) = eps;
+  if constexpr (VEC4) *reinterpret_cast<float4*>(a.eps_out + base) = eps;
   if (g == 0) a.s_out[b] = sa;
 }
 
@@ -297,13 +332,22 @@ __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restr
   out[idx] = c < cols ? f2bf(in[(size_t)r * cols + c]) : f2bf(0.0f);
 }
 
+template <bool VEC4>
 __global__ __launch_bounds__(256) void fill_normal_kernel(float* __restrict__ out, int per_sample, RngKey key,
                                                           uint32_t stream, uint32_t sample_offset) {
   const int g = blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
   if (g * 4 >= per_sample) return;
   const float4 n = philox_normal4((uint32_t)g, (uint32_t)b + sample_offset, stream, 0u, key.seed_lo, key.seed_hi);
-  *reinterpret_cast<float4*>(out + (size_t)b * per_sample + g * 4) = n;
+  float* dst = out + (size_t)b * per_sample + g * 4;
+  if constexpr (VEC4) {
+    *reinterpret_cast<float4*>(dst) = n;
+  } else {                       // per_sample not a multiple of 4: same draws, scalar stores, cut at the sample's end
+    const float v[4] = {n.x, n.y, n.z, n.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (g * 4 + i < per_sample) dst[i] = v[i];
+  }
 }
 
 __global__ __launch_bounds__(256) void swish_bwd_bf16_kernel(const bf16_t* __restrict__ pre,
@@ -326,9 +370,11 @@ int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_
 int launch_q_sample(const QSampleArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.x0 && a.alphas_prod_ext && a.xt_bf16 && a.eps_out && a.s_out, "q_sample: null pointer");
   SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && a.Cp >= a.C && a.T > 0, "q_sample: bad shape");
-  SMD_ARG_CHECK((a.S * a.C) % 4 == 0, "q_sample: S*C=%d must be a multiple of 4", a.S * a.C);
-  const int groups = a.S * a.C / 4;
-  hipLaunchKernelGGL(q_sample_kernel, dim3((groups + 255) / 256, a.B), dim3(256), 0, st, a);
+  SMD_ARG_CHECK(a.label_min == 0 || a.label_min == 1, "q_sample: label_min=%d", a.label_min);
+  const int groups = (a.S * a.C + 3) / 4;
+  const dim3 grid((groups + 255) / 256, a.B);
+  if ((a.S * a.C) % 4 == 0) hipLaunchKernelGGL(q_sample_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(q_sample_kernel<false>, grid, dim3(256), 0, st, a);
   SMD_LAUNCH_CHECK();
   return 0;
 }
@@ -387,9 +433,12 @@ int launch_cast_pad_bf16(const float* in, int rows, int cols, bf16_t* out, int l
 
 int launch_fill_normal(float* out, int B, int per_sample, RngKey key, uint32_t stream, uint32_t sample_offset,
                        hipStream_t st) {
-  SMD_ARG_CHECK(out && B > 0 && per_sample > 0 && per_sample % 4 == 0, "fill_normal: per_sample must be a multiple of 4");
-  hipLaunchKernelGGL(fill_normal_kernel, dim3((per_sample / 4 + 255) / 256, B), dim3(256), 0, st, out, per_sample,
-                     key, stream, sample_offset);
+  SMD_ARG_CHECK(out && B > 0 && per_sample > 0, "fill_normal: bad arguments");
+  const dim3 grid(((per_sample + 3) / 4 + 255) / 256, B);
+  if (per_sample % 4 == 0)
+    hipLaunchKernelGGL(fill_normal_kernel<true>, grid, dim3(256), 0, st, out, per_sample, key, stream, sample_offset);
+  else
+    hipLaunchKernelGGL(fill_normal_kernel<false>, grid, dim3(256), 0, st, out, per_sample, key, stream, sample_offset);
   SMD_LAUNCH_CHECK();
   return 0;
 }

@@ -110,6 +110,11 @@ class SmdEngine {
   // step); the side stream is joined at the end of loss_backward().  0 = single stream.
   int set_side_stream(int enable);
   void mark_w8_dirty() { w8_dirty_ = true; }
+  // diffusion_loss(continuous_noise=False), utils/losses.py:272-286: labels in [0, T) and, for label 0, a real uniform
+  // used_alpha in [alphas_prod[T], 1).  used_alphas (device, [B], may be null) overrides the label -> alpha lookup of the
+  // NEXT loss_backward calls until it is reset to null.
+  int label_min = 1;
+  void set_used_alphas(const float* a) { used_alphas_ = a; }
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
@@ -163,6 +168,7 @@ class SmdEngine {
   bf16_t* wpack_ = nullptr;
   float *grads_ = nullptr, *m_ = nullptr, *v_ = nullptr, *ema_ = nullptr, *metrics_ = nullptr;
   uint32_t* step_ptr_ = nullptr;
+  const float* used_alphas_ = nullptr;
   const float* coef_ = nullptr;
   const float* sqrt_ap_ = nullptr;
   const float* alphas_prod_ext_ = nullptr;

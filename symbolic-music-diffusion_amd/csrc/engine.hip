@@ -764,6 +764,7 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     q.x0 = x0; q.B = batch_; q.S = S; q.C = C; q.Cp = Cp_; q.T = d_.num_timesteps;
     q.alphas_prod_ext = alphas_prod_ext_;
     q.labels = labels; q.eps_in = eps_in; q.key = RngKey{seed_lo, seed_hi};
+    q.label_min = label_min; q.alpha_in = used_alphas_;
     q.step_ptr = step_ptr_; q.sample_offset = sample_offset;
     q.xt_bf16 = W.x_bf16; q.eps_out = W.eps; q.s_out = W.s;
     RC(launch_q_sample(q, st));

@@ -209,7 +209,9 @@ struct QSampleArgs {
   int B = 0, S = 0, C = 0, Cp = 0;       // Cp: padded row length of xt_bf16
   int T = 0;
   const float* alphas_prod_ext = nullptr; // [T+1] = [1, cumprod(1-beta)]
-  const int* labels = nullptr;            // [B] explicit labels in [1,T] or null -> Philox
+  const int* labels = nullptr;            // [B] explicit labels in [0,T] or null -> Philox
+  int label_min = 1;                      // Philox labels in [label_min, label_min + T): 1 = continuous_noise, 0 = not
+  const float* alpha_in = nullptr;        // [B] explicit used_alphas (utils/losses.py:283-286) or null -> from the label
   const float* eps_in = nullptr;          // explicit eps or null -> Philox
   RngKey key{0, 0};
   const uint32_t* step_ptr = nullptr;     // device step counter (RNG stream offset), may be null

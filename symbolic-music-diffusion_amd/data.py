@@ -49,6 +49,18 @@ def slice_transform(batch, slice_idx=None, dim_weights=None):
     return batch
 
 
+def data_transform(batch, pca=None):
+    """input_pipeline.py:51-75 ('vae' problem): the optional PCA projection, rows flattened for >2-D examples."""
+    if pca is not None:
+        batch = np.asarray(batch)
+        if batch.ndim > 2:
+            shape = batch.shape
+            batch = pca.transform(batch.reshape(shape[0], -1)).reshape(*shape)
+        else:
+            batch = pca.transform(batch)
+    return batch
+
+
 def inverse_data_transform(batch, normalize=True, pca=None, data_min=0.0, data_max=1.0, slice_idx=None,
                            dim_weights=None, out_channels=512):
     """input_pipeline.py:78-110.  The non-selected latent dims are filled with an unseeded
@@ -73,26 +85,44 @@ class ArrayLatents:
     tf.data datasets: ``examples`` = batches per epoch (:359,381), ``min`` / ``max`` (:424-431)."""
 
     def __init__(self, array: np.ndarray, batch_size: int, data_min: float = -1.0, data_max: float = 1.0,
-                 drop_remainder: bool = True, device: Optional[str] = None, rank: int = 0, world_size: int = 1):
+                 drop_remainder: bool = True, device: Optional[str] = None, rank: int = 0, world_size: int = 1,
+                 shuffle: bool = False, seed: int = 0):
+        """``shuffle``: a fresh seeded permutation of the WHOLE split every epoch (the reference reshuffles its files and an
+        8*batch buffer per epoch, utils/data_utils.py:159-183); with world_size > 1 every rank holds the split and takes
+        its own slice of the same global permutation, so the ranks stay disjoint.  Unshuffled: one contiguous shard."""
         array = np.ascontiguousarray(array, dtype=np.float32)
-        if world_size > 1:                      # disjoint contiguous shard per rank
-            per = len(array) // world_size
+        self.shuffle, self.seed, self.epoch = bool(shuffle), int(seed), 0
+        self.rank, self.world_size = int(rank), int(world_size)
+        per = len(array) // world_size
+        if world_size > 1 and not shuffle:      # disjoint contiguous shard per rank
             array = array[rank * per:(rank + 1) * per]
         self.array = torch.from_numpy(array)
         if device is not None:
             self.array = self.array.to(device)   # resident in HBM: no per-step H2D copy
         self.batch_size = batch_size
-        n = len(array)
-        self.examples = n // batch_size if drop_remainder else -(-n // batch_size)
+        self.per_rank = per
+        self.examples = per // batch_size if drop_remainder else -(-per // batch_size)
         self.min, self.max = data_min, data_max
 
     @property
     def sample_shape(self):
         return tuple(self.array.shape[1:])
 
+    def epoch_order(self, epoch: int) -> torch.Tensor:
+        """This rank's example indices for ``epoch``: slice [rank*per, (rank+1)*per) of randperm(N; seed, epoch)."""
+        g = torch.Generator().manual_seed((self.seed * 1000003 + epoch) & 0x7FFFFFFFFFFFFFFF)
+        perm = torch.randperm(len(self.array), generator=g)
+        return perm[self.rank * self.per_rank:(self.rank + 1) * self.per_rank]
+
     def __iter__(self) -> Iterator[torch.Tensor]:
+        if not self.shuffle:
+            for i in range(self.examples):
+                yield self.array[i * self.batch_size:(i + 1) * self.batch_size]
+            return
+        idx = self.epoch_order(self.epoch).to(self.array.device)
+        self.epoch += 1
         for i in range(self.examples):
-            yield self.array[i * self.batch_size:(i + 1) * self.batch_size]
+            yield self.array.index_select(0, idx[i * self.batch_size:(i + 1) * self.batch_size])
 
     def __len__(self):
         return self.examples
@@ -138,17 +168,20 @@ def _config_name(*ckpts: str) -> str:
 
 def open_dataset(path: str, batch_size: int, sample_shape: Sequence[int], device=None, rank=0, world_size=1,
                  normalize=True, slice_idx=None, dim_weights=None, data_shape: Optional[Sequence[int]] = None,
-                 pca_ckpt: str = "", slice_ckpt: str = "", dim_weights_ckpt: str = "", cache: bool = True):
+                 pca_ckpt: str = "", slice_ckpt: str = "", dim_weights_ckpt: str = "", cache: bool = True,
+                 shuffle: bool = True, seed: int = 0):
     """``--dataset``: the reference's ``{train,eval}-*.tfrecord`` shards (input_pipeline.py:126-139; read without
     TensorFlow, tfrecord.py) or {train,eval}.npy / .pkl arrays of raw latents (N, *data_shape).
 
-    Order of operations as in get_dataset (:113-235): slice / weight transform -> batch with drop_remainder ->
-    per-split min / max (cached under ``{dataset}/cache``) -> each split normalised with ITS OWN min / max
-    (:189-208).  Records are read in sorted file order (the reference shuffles files and an 8*batch buffer with
-    an unseeded tf.data shuffle)."""
+    Order of operations as in get_dataset (:113-235): PCA (``--pca_ckpt``, a pickled object with .transform /
+    .inverse_transform) -> slice / weight transform -> batch with drop_remainder -> per-split min / max (cached under
+    ``{dataset}/cache``) -> each split normalised with ITS OWN min / max (:189-208).  Records are read in sorted file
+    order; the training split is then reshuffled every epoch with a permutation seeded by (seed, epoch) (the reference
+    shuffles files and an 8*batch buffer with an unseeded tf.data shuffle); the eval split stays ordered."""
     from . import tfrecord
     path = os.path.expanduser(path)
     raw_shape = tuple(int(v) for v in (data_shape if data_shape is not None else sample_shape))
+    pca = load(os.path.expanduser(pca_ckpt)) if pca_ckpt else None              # input_pipeline.py:144
     out = []
     for split in ("train", "eval"):
         arr = None
@@ -162,7 +195,8 @@ def open_dataset(path: str, batch_size: int, sample_shape: Sequence[int], device
                     break
         if arr is None:
             raise FileNotFoundError(f"{path}: neither {split}-*.tfrecord nor {split}.npy|.pkl found (or pass --synthetic)")
-        arr = slice_transform(np.asarray(arr, np.float32), slice_idx, dim_weights)
+        arr = np.asarray(data_transform(np.asarray(arr, np.float32), pca), np.float32)       # :159-166
+        arr = slice_transform(arr, slice_idx, dim_weights)
         out.append(arr[:(len(arr) // batch_size) * batch_size])                 # batch(drop_remainder=True)
     config = _config_name(pca_ckpt, slice_ckpt, dim_weights_ckpt)
     sets = []
@@ -173,5 +207,6 @@ def open_dataset(path: str, batch_size: int, sample_shape: Sequence[int], device
             arr = normalize_dataset(arr, dmin, dmax)
         is_train = split == "train"
         sets.append(ArrayLatents(arr.reshape(len(arr), *sample_shape), batch_size, float(dmin), float(dmax), True, device,
-                                 rank if is_train else 0, world_size if is_train else 1))
+                                 rank if is_train else 0, world_size if is_train else 1,
+                                 shuffle=shuffle and is_train, seed=seed))
     return sets[0], sets[1]

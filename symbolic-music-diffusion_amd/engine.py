@@ -94,6 +94,7 @@ class Engine:
         # engines sharing one operand pack: a weight refresh through any handle invalidates every handle's e4m3 copies
         self._wstate = share_params_with._wstate if share_params_with is not None else {"ver": 0}
         self._wseen = -1
+        self._label_min = 1
         self.grads = self.m = self.v = self.ema = None
         self.step_counter = None
         self.metrics = None
@@ -231,8 +232,16 @@ class Engine:
     # ------------------------------------------------------------------ training
     def loss_backward(self, x0: torch.Tensor, labels: Optional[torch.Tensor] = None,
                       eps: Optional[torch.Tensor] = None, seed: int = 0, sample_offset: int = 0,
-                      global_batch: Optional[int] = None, stage: int = 0) -> None:
+                      global_batch: Optional[int] = None, stage: int = 0, *, used_alphas: Optional[torch.Tensor] = None,
+                      continuous_noise: bool = True) -> None:
+        """``continuous_noise=False``: labels in [0, T) (utils/losses.py:272-275) and a real uniform used_alpha for label 0;
+        ``used_alphas`` ([B] floats) passes the draws of :283-286 explicitly."""
         B = x0.shape[0] if x0 is not None else self.batch
+        lm = 1 if continuous_noise else 0
+        if lm != self._label_min:
+            _lib.check(self.L.smd_engine_set_option(self.h, b"label_min", lm), "set_option label_min")
+            self._label_min = lm
+        _lib.check(self.L.smd_engine_set_used_alphas(self.h, _ptr(used_alphas)), "set_used_alphas")
         gb = B if global_batch is None else global_batch
         inv = 1.0 / (gb * float(np.prod(self.cfg.sample_shape)))
         self._sync_fp8_weights()

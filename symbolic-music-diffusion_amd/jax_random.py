@@ -136,8 +136,9 @@ def diffusion_loss_draws(rng: ThreefryKey, local_shape: Sequence[int], num_sigma
                          continuous_noise: bool = True, sample_offset: int = 0,
                          global_batch: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(labels, eps) of utils/losses.py:271-294 for this rank's rows [sample_offset, sample_offset + B) of a
-    global batch.  The uniform of :283-286 is degenerate (minval > maxval returns minval) and draws nothing that
-    matters: the engine's label -> alpha-bar table already holds alphas_prod_ext[label - 1]."""
+    global batch.  With continuous_noise=True the uniform of :283-286 is degenerate (minval > maxval returns minval)
+    and draws nothing that matters: the engine's label -> alpha-bar table already holds alphas_prod_ext[label - 1].
+    With continuous_noise=False label 0 is possible and its uniform is real: see ``diffusion_loss_used_alphas``."""
     _rng, label_rng, sample_rng = split(rng, 3)
     B = int(local_shape[0])
     gb = B if global_batch is None else int(global_batch)
@@ -146,6 +147,24 @@ def diffusion_loss_draws(rng: ThreefryKey, local_shape: Sequence[int], num_sigma
                      offset=sample_offset)
     eps = normal(sample_rng, tuple(local_shape), device, n_total=gb * per, offset=sample_offset * per)
     return labels, eps
+
+
+def diffusion_loss_used_alphas(rng: ThreefryKey, labels: torch.Tensor, alphas_prod_ext: torch.Tensor, *,
+                               sample_offset: int = 0, global_batch: Optional[int] = None) -> torch.Tensor:
+    """used_alphas of utils/losses.py:282-286 for this rank's labels: ``rng, noise_rng = split(rng)`` on the first
+    output of the 3-way split, then uniform(noise_rng, (B,), minval=alphas_prod'[labels - 1], maxval=alphas_prod'[labels])
+    = max(minval, u01 * (maxval - minval) + minval).  labels - 1 = -1 wraps to the last entry (alphas_prod[T]) exactly as
+    the jnp indexing does, which is what makes label 0 a real draw in [alphas_prod[T], 1)."""
+    first, _label_rng, _sample_rng = split(rng, 3)
+    _rng, noise_rng = split(first)
+    B = int(labels.shape[0])
+    gb = B if global_batch is None else int(global_batch)
+    u = uniform(noise_rng, (B,), labels.device, 0.0, 1.0, n_total=gb, offset=sample_offset)
+    T1 = int(alphas_prod_ext.shape[0])
+    lab = labels.long()
+    lo = alphas_prod_ext[(lab - 1) % T1]
+    hi = alphas_prod_ext[lab % T1]
+    return torch.maximum(lo, u * (hi - lo) + lo).contiguous()
 
 
 def sampler_key_tables(ld_rng: ThreefryKey, iterations: int) -> Tuple[np.ndarray, np.ndarray]:

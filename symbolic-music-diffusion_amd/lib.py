@@ -67,6 +67,7 @@ _SIGS = {
     "smd_engine_forward": (C.c_int, [c_void] * 5),
     "smd_engine_loss_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_u32, c_u32, c_u32, C.c_float,
                                            C.c_int, c_void]),
+    "smd_engine_set_used_alphas": (C.c_int, [c_void, c_void]),
     "smd_engine_loss_per_sample": (c_void, [c_void]),
     "smd_engine_pred": (c_void, [c_void]),
     "smd_engine_optimizer_step": (C.c_int, [c_void, C.POINTER(TrainHyper), c_void]),
@@ -112,6 +113,11 @@ _SIGS = {
     "smd_threefry_uniform": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, C.c_float, C.c_float, c_void]),
     "smd_threefry_normal": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, c_void, c_void, C.c_int, C.c_int, c_void]),
     "smd_threefry_randint": (C.c_int, [c_void, c_i64, c_i64, c_i64, c_u32, c_u32, C.c_int32, C.c_int32, c_void]),
+    "smd_q_sample": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void, C.c_int, c_void, c_void,
+                               c_u32, c_u32, c_void, c_u32, c_void, c_void, c_void, c_void]),
+    "smd_mse_fwd_bwd": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_void, c_void, c_void]),
+    "smd_adam_clip_ema": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.POINTER(TrainHyper), c_void, c_void,
+                                    c_void, c_void]),
     "smd_rng_normal": (C.c_int, [c_void, C.c_int, C.c_int, c_u32, c_u32, c_u32, c_u32, c_void]),
     "smd_cast_pad_bf16": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
     "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_u32,

@@ -163,21 +163,26 @@ def _ensure_schedule(engine: Engine, betas, with_sampler: bool) -> None:
 
 
 def diffusion_loss(batch, model: Model, betas, rng: PRNGKey, continuous_noise=False, reduction="mean", *,
-                   labels=None, eps=None):
+                   labels=None, eps=None, used_alphas=None):
     """utils/losses.py:250-308 (forward only; the training step fuses it with the backward).
     ``labels`` / ``eps`` pass the draws of :272-275 / :294 explicitly (parity mode); otherwise they
-    come from the engine's Philox streams keyed by ``rng``.  The continuous_noise flag has no effect
-    in the reference either: the discrete branch is commented out (:280-302)."""
-    del continuous_noise
+    come from the engine's Philox streams keyed by ``rng`` (or, with a ThreefryKey, are the reference's own).
+    continuous_noise only moves the label range (:272-275): True -> [1, T], every uniform of :283-286 degenerates to its
+    minval; False -> [0, T), where label 0 wraps to minval = alphas_prod[T] < maxval = 1 and is a real uniform draw.
+    ``used_alphas`` passes those draws explicitly.  (The discrete-conditioning branch itself is commented out upstream.)"""
     eng = model.train_engine(ema=False)
     batch = torch.as_tensor(batch).to(eng.device, torch.float32).contiguous()
     _ensure_schedule(eng, betas, with_sampler=False)
     eng.bind(batch.shape[0], training=True)
     lab = None if labels is None else torch.as_tensor(labels).to(eng.device, torch.int32).contiguous()
     e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
+    ua = None if used_alphas is None else torch.as_tensor(used_alphas).to(eng.device, torch.float32).contiguous()
     if isinstance(rng, ThreefryKey) and lab is None and e is None:
-        lab, e = _jr.diffusion_loss_draws(rng, tuple(batch.shape), len(betas), eng.device)      # :271-294
-    eng.loss_backward(batch, lab, e, seed=rng.seed, stage=3)
+        lab, e = _jr.diffusion_loss_draws(rng, tuple(batch.shape), len(betas), eng.device,
+                                          continuous_noise=bool(continuous_noise))              # :271-294
+        if not continuous_noise and ua is None:
+            ua = _jr.diffusion_loss_used_alphas(rng, lab, eng._sched_tensors["ape"])            # :282-286
+    eng.loss_backward(batch, lab, e, seed=rng.seed, stage=3, used_alphas=ua, continuous_noise=bool(continuous_noise))
     loss = eng.loss_per_sample().clone()
     assert loss.shape == batch.shape[:1]                                          # utils/losses.py:306
     return reduce_fn(loss, reduction)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .engine import Engine
-from .jax_random import ThreefryKey, diffusion_loss_draws
+from .jax_random import ThreefryKey, diffusion_loss_draws, diffusion_loss_used_alphas
 from .ncsn import Model, PRNGKey, _ensure_schedule, diffusion_loss
 
 
@@ -69,11 +69,12 @@ class LazyMetrics(dict):
 def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, learning_rate: float, *,
                grad_clip: float = 1.0, mu: float = 0.999, labels=None, eps=None, comm: "Optional[GradComm]" = None,
                lr_gamma: float = 1.0, lr_interval: int = 1, sample_offset: int = 0,
-               global_batch: Optional[int] = None):
+               global_batch: Optional[int] = None, continuous_noise: bool = True, used_alphas=None):
     """train_ncsn.py:260-288: value_and_grad(mean diffusion_loss) -> clip_grads -> Adam
     (+ EMA, fused).  ``learning_rate`` is the step's LR as in the reference; pass ``lr_gamma`` /
     ``lr_interval`` instead to let the kernel evaluate the stepped schedule from its own step
-    counter (learning_rate is then lr0).  Returns (optimizer, metrics{'loss','grad','lr'})."""
+    counter (learning_rate is then lr0).  ``continuous_noise`` is FLAGS.continuous_noise (:278): False draws the labels
+    in [0, T) and gives label 0 its real uniform noise level (utils/losses.py:272-286).  Returns (optimizer, metrics{'loss','grad','lr'})."""
     if objective is not diffusion_loss and getattr(objective, "__name__", "") != "diffusion_loss":
         raise ValueError("the HIP engine implements the 'ddpm' objective (diffusion_loss) only")
     eng = optimizer.engine
@@ -84,16 +85,21 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
     world = 1 if comm is None else comm.world_size
     gb = batch.shape[0] * world if global_batch is None else global_batch
+    ua = None if used_alphas is None else torch.as_tensor(used_alphas).to(eng.device, torch.float32).contiguous()
     if isinstance(rng, ThreefryKey) and lab is None and e is None:
         # the reference's own draws (utils/losses.py:271-294) for this rank's rows of the global batch
         lab, e = diffusion_loss_draws(rng, tuple(batch.shape), len(sigmas), eng.device, sample_offset=sample_offset,
-                                      global_batch=gb)
+                                      global_batch=gb, continuous_noise=continuous_noise)
+        if not continuous_noise and ua is None:
+            ua = diffusion_loss_used_alphas(rng, lab, eng._sched_tensors["ape"], sample_offset=sample_offset,
+                                            global_batch=gb)
+    kw = dict(seed=rng.seed, sample_offset=sample_offset, global_batch=gb, used_alphas=ua, continuous_noise=continuous_noise)
     if comm is None:
-        eng.loss_backward(batch, lab, e, seed=rng.seed, sample_offset=sample_offset, global_batch=gb, stage=0)
+        eng.loss_backward(batch, lab, e, stage=0, **kw)
     else:
-        eng.loss_backward(batch, lab, e, seed=rng.seed, sample_offset=sample_offset, global_batch=gb, stage=1)
+        eng.loss_backward(batch, lab, e, stage=1, **kw)
         comm.reduce_async(eng.grads[eng.head_offset:])          # output-stage gradients are final
-        eng.loss_backward(None, None, None, seed=rng.seed, sample_offset=sample_offset, global_batch=gb, stage=2)
+        eng.loss_backward(None, None, None, stage=2, **kw)
         comm.reduce_async(eng.grads[:eng.head_offset])
         comm.wait()
     # gradients were scaled by 1/(global_batch*S*C) at the loss, so the all-reduce SUM is the global mean
@@ -103,19 +109,19 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     return optimizer, metrics
 
 
-def eval_step(objective, batch, model: Model, sigmas, rng: PRNGKey):
+def eval_step(objective, batch, model: Model, sigmas, rng: PRNGKey, continuous_noise: bool = True):
     """train_ncsn.py:206-221: summed loss of one batch."""
-    return objective(batch, model, sigmas, rng, True, "sum")
+    return objective(batch, model, sigmas, rng, continuous_noise, "sum")
 
 
-def evaluate(dataset, model: Model, sigmas, rng: PRNGKey):
+def evaluate(dataset, model: Model, sigmas, rng: PRNGKey, continuous_noise: bool = True):
     """train_ncsn.py:224-257: mean per-example loss over the dataset (iterable of batches)."""
     from .ncsn import split
     count, total = 0, 0.0
     for inputs in dataset:
         count += inputs.shape[0]
         rng, eval_rng = split(rng)
-        total += float(eval_step(diffusion_loss, inputs, model, sigmas, eval_rng))
+        total += float(eval_step(diffusion_loss, inputs, model, sigmas, eval_rng, continuous_noise))
     return {"loss": total / max(count, 1)}
 
 

@@ -121,7 +121,12 @@ def test_open_dataset_from_tfrecords_follows_the_reference_order(tmp_path):
     assert tr.min == pytest.approx(float(kept_t.min())) and tr.max == pytest.approx(float(kept_t.max()))
     assert ev.min == pytest.approx(float(kept_e.min())) and ev.max == pytest.approx(float(kept_e.max()))   # its own range
     want = O.normalize_dataset(kept_t, np.float32(kept_t.min()), np.float32(kept_t.max()))
-    assert np.allclose(np.concatenate([b.numpy() for b in tr]), want, atol=1e-6)
+    got = np.concatenate([b.numpy() for b in tr])                                # the training split: seeded reshuffle
+    order = tr.epoch_order(0).numpy()
+    assert sorted(order.tolist()) == list(range(20)) and np.allclose(got, want[order], atol=1e-6)
+    plain, _ = D.open_dataset(str(tmp_path), 4, (4, 4), None, 0, 1, True, slice_idx, None, data_shape=(4, 16),
+                              slice_ckpt="/x/mel_slice.pkl", shuffle=False)
+    assert np.allclose(np.concatenate([b.numpy() for b in plain]), want, atol=1e-6)
     assert float(tr.array.min()) == -1.0 and float(tr.array.max()) == 1.0
     # the reference's cache files ({dataset}/cache/{split}_{config}_{min,max}.pkl) exist and win on the next open
     for split in ("train", "eval"):
@@ -132,7 +137,7 @@ def test_open_dataset_from_tfrecords_follows_the_reference_order(tmp_path):
                             slice_ckpt="/x/mel_slice.pkl")
     assert tr2.min == -100.0
     # inverse transform puts the slice back into 512-wide rows (random fill elsewhere, float64) -- :78-110
-    inv = D.inverse_data_transform(np.concatenate([b.numpy() for b in tr]), True, None, tr.min, tr.max, slice_idx, None,
+    inv = D.inverse_data_transform(np.concatenate([b.numpy() for b in plain]), True, None, tr.min, tr.max, slice_idx, None,
                                    out_channels=16)
     assert inv.dtype == np.float64 and inv.shape == (20, 4, 16)
     assert np.allclose(inv[..., slice_idx], kept_t, atol=1e-5)

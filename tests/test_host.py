@@ -107,6 +107,91 @@ def test_data_transforms_match_oracle(tmp_path):
     assert a0.examples == 2 and not torch.equal(next(iter(a0)), next(iter(a1)))
 
 
+def test_training_split_is_reshuffled_every_epoch_and_ranks_stay_disjoint():
+    """utils/data_utils.py:159-183 (shuffle=True for the training files + an 8*batch buffer, new order every epoch)."""
+    from smd_amd import data
+    arr = np.arange(96, dtype=np.float32).reshape(96, 1) * np.ones((1, 4), np.float32)
+    ds = data.ArrayLatents(arr, 8, shuffle=True, seed=5)
+    e0 = torch.cat(list(ds))[:, 0]
+    e1 = torch.cat(list(ds))[:, 0]
+    assert ds.examples == 12 and len(e0) == 96
+    assert sorted(e0.tolist()) == list(range(96)) and sorted(e1.tolist()) == list(range(96))     # a permutation each
+    assert not torch.equal(e0, e1) and not torch.equal(e0, torch.arange(96.0))                   # and a new one each epoch
+    again = data.ArrayLatents(arr, 8, shuffle=True, seed=5)
+    assert torch.equal(torch.cat(list(again))[:, 0], e0)                                         # seeded
+    assert not torch.equal(torch.cat(list(data.ArrayLatents(arr, 8, shuffle=True, seed=6)))[:, 0], e0)
+    halves = [data.ArrayLatents(arr, 8, rank=r, world_size=2, shuffle=True, seed=5) for r in range(2)]
+    for _epoch in range(2):
+        a, b = (torch.cat(list(h))[:, 0] for h in halves)
+        assert len(a) == len(b) == 48 and sorted(a.tolist() + b.tolist()) == list(range(96))     # global permutation, disjoint
+    plain = data.ArrayLatents(arr, 8)
+    assert torch.equal(torch.cat(list(plain))[:, 0], torch.arange(96.0))                         # eval split: file order
+    assert torch.equal(torch.cat(list(plain))[:, 0], torch.arange(96.0))
+
+
+class _Rotation:
+    """Stand-in for the pickled sklearn PCA of --pca_ckpt: an orthogonal map around a mean."""
+
+    def __init__(self, d, seed):
+        q, _ = np.linalg.qr(np.random.default_rng(seed).normal(size=(d, d)))
+        self.q, self.mean = q.astype(np.float32), np.float32(0.3)
+
+    def transform(self, x):
+        return (x - self.mean) @ self.q
+
+    def inverse_transform(self, x):
+        return x @ self.q.T + self.mean
+
+
+def test_open_dataset_applies_pca_slice_normalise_in_reference_order(tmp_path):
+    """input_pipeline.py:144,159-181,189-208: PCA -> dim weights / slice -> per-split min/max -> normalise."""
+    from smd_amd import data
+    rng = np.random.default_rng(1)
+    tr = rng.normal(size=(40, 16)).astype(np.float32)
+    ev = rng.normal(size=(24, 16)).astype(np.float32) * 2
+    np.save(tmp_path / "train.npy", tr)
+    np.save(tmp_path / "eval.npy", ev)
+    pca = _Rotation(16, 3)
+    data.save(pca, str(tmp_path / "pca.pkl"))
+    idx = np.array([1, 4, 5, 9, 14])
+    w = rng.uniform(0.5, 2, size=16).astype(np.float32)
+    train, valid = data.open_dataset(str(tmp_path), 8, (5,), data_shape=(16,), slice_idx=idx, dim_weights=w,
+                                     pca_ckpt=str(tmp_path / "pca.pkl"), cache=False, shuffle=False)
+    for ds, raw in ((train, tr), (valid, ev)):
+        want = np.take(pca.transform(raw) * w, idx, axis=-1)
+        want = want[:(len(want) // 8) * 8]
+        assert np.isclose(ds.min, want.min()) and np.isclose(ds.max, want.max())
+        got = torch.cat(list(ds)).numpy()
+        assert np.allclose(got, O.normalize_dataset(want, want.min(), want.max()), atol=1e-6)
+    # and back: un-normalise -> inverse PCA (sample_ncsn.py:456-468 passes the same object)
+    full, _ = data.open_dataset(str(tmp_path), 8, (16,), pca_ckpt=str(tmp_path / "pca.pkl"), cache=False, shuffle=False)
+    back = data.inverse_data_transform(torch.cat(list(full)).numpy(), True, pca, full.min, full.max)
+    assert np.allclose(back, tr, atol=1e-4)
+    shuffled, _ = data.open_dataset(str(tmp_path), 8, (16,), cache=False, seed=3)
+    assert shuffled.shuffle and not _.shuffle
+
+
+def test_oracle_label_zero_takes_a_real_uniform_noise_level():
+    """utils/losses.py:272-286 with continuous_noise=False: labels in [0, T); label 0 -> uniform in [alphas_prod[T], 1);
+    every other label -> its (degenerate) minval alphas_prod'[l - 1]."""
+    betas = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
+    ap = np.concatenate([[1.0], np.cumprod(1 - betas.astype(np.float64))])
+    key = O.jax_prngkey(11)
+    labels, _eps = O.jax_diffusion_loss_draws(key, (4096, 2), 1000, continuous_noise=False)
+    assert labels.min() == 0 and labels.max() == 999
+    labels[:3] = 0
+    u = O.jax_diffusion_loss_u01(key, 4096)
+    assert u.dtype == np.float32 and 0 <= u.min() and u.max() < 1 and abs(u.mean() - 0.5) < 0.02
+    a = O.used_alphas_from_labels(betas, labels, u)
+    z = labels == 0
+    assert np.allclose(a[~z], ap[labels[~z] - 1], rtol=1e-5)
+    assert np.allclose(a[z], ap[1000] + u[z] * (1 - ap[1000]), rtol=1e-5) and (a[z] >= ap[1000] * (1 - 1e-6)).all() and (a[z] < 1).all()
+    with pytest.raises(ValueError):
+        O.used_alphas_from_labels(betas, labels)
+    lab1, _ = O.jax_diffusion_loss_draws(key, (64, 2), 1000, continuous_noise=True)
+    assert np.array_equal(O.used_alphas_from_labels(betas, lab1), O.used_alphas_from_labels(betas, lab1, u[:64]))
+
+
 def test_early_stopping_and_rng_split():
     from smd_amd import ncsn
     from smd_amd.train_utils import EarlyStopping

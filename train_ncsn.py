@@ -49,7 +49,7 @@ def build_datasets(FLAGS, sample_shape, device, rank, world):
         train, valid = data.open_dataset(FLAGS.dataset, FLAGS.batch_size, sample_shape, device, rank, world,
                                          FLAGS.normalize, slice_idx, dim_weights, data_shape=[int(v) for v in FLAGS.data_shape],
                                          pca_ckpt=FLAGS.pca_ckpt, slice_ckpt=FLAGS.slice_ckpt,
-                                         dim_weights_ckpt=FLAGS.dim_weights_ckpt)
+                                         dim_weights_ckpt=FLAGS.dim_weights_ckpt, shuffle=True, seed=FLAGS.seed)
     return train, valid, slice_idx, dim_weights
 
 
@@ -99,7 +99,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                 ncsn.diffusion_loss, batch, optimizer, sigmas, train_rng, FLAGS.learning_rate,
                 grad_clip=FLAGS.grad_clip, mu=FLAGS.mu, comm=comm, lr_gamma=FLAGS.lr_gamma,
                 lr_interval=FLAGS.lr_schedule_interval, sample_offset=rank * FLAGS.batch_size,
-                global_batch=FLAGS.batch_size * world)
+                global_batch=FLAGS.batch_size * world, continuous_noise=FLAGS.continuous_noise)
             if FLAGS.ema:
                 ema = ema.update(optimizer.target)                                # :364-365 (fused: no-op)
 
@@ -115,7 +115,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                 sampling_step += 1
                 rng, eval_rng = ncsn.split(rng)
                 if rank == 0:
-                    eval_metrics = evaluate(valid_batches, optimizer.target, sigmas, eval_rng)
+                    eval_metrics = evaluate(valid_batches, optimizer.target, sigmas, eval_rng, FLAGS.continuous_noise)
                     train_utils.log_metrics(eval_metrics, global_step, train_batches.examples * FLAGS.epochs,
                                             summary_writer=eval_writer, verbose=verbose)
                     improved, early_stop = early_stop.update(eval_metrics["loss"])            # :393
