@@ -166,6 +166,78 @@ def test_flax_checkpoint_written_elsewhere_is_read(tmp_path):
     assert int(dst.step_counter) == 77
 
 
+# engine tensor -> (leaf number in tests/golden/make_flax_fixture.py's LEAVES, column range of the engine tensor)
+_FIXTURE_LEAVES = {
+    "in_proj.kernel": [(0, None)], "in_proj.bias": [(1, None)],
+    "film.0.fc1.kernel": [(2, None)], "film.0.fc1.bias": [(3, None)],
+    "film.0.fc2.kernel": [(4, None)], "film.0.fc2.bias": [(5, None)],
+    "film.0.ss.kernel": [(6, (0, 8)), (8, (8, 16))], "film.0.ss.bias": [(7, (0, 8)), (9, (8, 16))],      # [scale | shift]
+    "res.0.ln1.scale": [(10, None)], "res.0.ln1.bias": [(11, None)],
+    "res.0.fc1.kernel": [(12, None)], "res.0.fc1.bias": [(13, None)],
+    "res.0.ln2.scale": [(14, None)], "res.0.ln2.bias": [(15, None)],
+    "res.0.fc2.kernel": [(16, None)], "res.0.fc2.bias": [(17, None)],
+    "ln_o.scale": [(18, None)], "ln_o.bias": [(19, None)],
+    "out_proj.kernel": [(20, None)], "out_proj.bias": [(21, None)],
+}
+
+
+def test_hand_assembled_flax_checkpoint_bytes_are_read(tmp_path):
+    """tests/golden/flax_dense_ddpm_tiny.msgpack was assembled byte by byte from the msgpack spec and the flax.serialization
+    layout (tests/golden/make_flax_fixture.py: no msgpack library, none of this package) -- the file
+    flax.training.checkpoints.save_checkpoint writes at /root/reference/train_ncsn.py:395-399 and sample_ncsn.py:331-342
+    restores.  Leaf n holds n + i/1024; Adam moments -value / 2*value; EMA value + 100."""
+    import shutil
+    import smd_amd.checkpoint as CK
+    import smd_amd.flax_io as FI
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flax_dense_ddpm_tiny.msgpack")
+    cfg = O.NetConfig(architecture="DenseDDPM", data_channels=4, num_layers=1, mlp_dims=8, film_channels=4)
+    assert FI.is_flax_file(src)
+    sd = FI.read_file(src)
+    assert set(sd) == {"0", "1", "2"} and FI.detect_naming(sd["0"]["target"]["params"], cfg)[0] == "shared"
+    template = {n: tuple(sh) for n, sh in O.param_spec(cfg)}
+    params, m, v, step, ema, mu, es = FI.split_state_dict(sd, cfg, template)
+    assert step == 4321 and mu == 0.999
+    assert es == dict(min_delta=0, patience=1, best_metric=0.0625, patience_count=1, should_stop=False)
+    assert set(params) == set(_FIXTURE_LEAVES) == set(template)
+    for name, parts in _FIXTURE_LEAVES.items():
+        shape = template[name]
+        for leaf, cols in parts:
+            sub = shape if cols is None else shape[:-1] + (cols[1] - cols[0],)
+            want = (np.float32(leaf) + np.arange(int(np.prod(sub)), dtype=np.float32) / np.float32(1024)).reshape(sub)
+            pick = (lambda a: a) if cols is None else (lambda a: a[..., cols[0]:cols[1]])
+            assert params[name].dtype == np.float32 and np.array_equal(pick(params[name]), want), name
+            assert np.array_equal(pick(m[name]), -want) and np.array_equal(pick(v[name]), 2 * want), name
+            assert np.array_equal(pick(ema[name]), want + np.float32(100)), name
+    # and through the checkpoint layer: checkpoint_<step> in a model dir restores parameters, moments, step, EMA
+    shutil.copy(src, tmp_path / "checkpoint_4321")
+
+    class TinyEngine(StubEngine):
+        def __init__(self):
+            self.cfg, self.device = cfg, torch.device("cpu")
+            self.tensor_table, off = [], 0
+            for name, shape in O.param_spec(cfg):
+                self.tensor_table.append((name, off, tuple(shape)))
+                off += int(np.prod(shape))
+            self.params, self.grads = torch.zeros(off), torch.zeros(off)
+            self.m, self.v, self.ema = torch.zeros(off), torch.zeros(off), torch.zeros(off)
+            self.step_counter = torch.tensor([0], dtype=torch.int32)
+
+    eng = TinyEngine()
+    found, stop = CK.restore_checkpoint(str(tmp_path), eng)
+    assert found and stop.best_metric == 0.0625 and stop.patience_count == 1 and int(eng.step_counter) == 4321
+    views = eng.named_views()
+    assert float(views["in_proj.kernel"][0, 1]) == np.float32(1 / 1024) and float(views["out_proj.bias"][3]) == 21 + 3 / 1024
+    assert torch.equal(eng.m, -eng.params) and torch.equal(eng.v, 2 * eng.params) and torch.equal(eng.ema, eng.params + 100)
+    eng2 = TinyEngine()
+    assert CK.load_ema_params(str(tmp_path), eng2) and torch.equal(eng2.params, eng.ema)     # sample_ncsn.py:338-342
+    # our writer reproduces the hand-assembled bytes exactly (same map order, same minimal encodings)
+    named = lambda flat: {k: t.numpy() for k, t in eng.named_views(flat).items()}
+    again = FI.checkpoint_state_dict(cfg, named(eng.params), named(eng.m), named(eng.v), 4321, named(eng.ema), 0.999, es)
+    srt = lambda d: {k: srt(d[k]) if isinstance(d[k], dict) else d[k] for k in sorted(d)}
+    with open(src, "rb") as f:
+        assert FI.to_bytes(srt(again)) == f.read()
+
+
 def test_host_threefry_key_algebra_matches_the_restatement():
     import smd_amd.jax_random as J
     k = J.PRNGKey(0)
