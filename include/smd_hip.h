@@ -131,6 +131,30 @@ int smd_engine_init_state(smd_engine* e, float* x, uint32_t seed_lo, uint32_t se
 int smd_engine_load_state(smd_engine* e, const float* x, void* stream);
 int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream);
 
+/* One Langevin update of annealed_langevin_dynamics / consistent_langevin_dynamics (utils/ebm_utils.py:131-164, 231-253):
+ *   next = x + alpha * grad + noise_coef * z;  with infill: next = next (1 - mask) + (infill_samples + infill_sigma * zi) mask.
+ * grad = model(state, sigma) comes from smd_engine_forward.  z / zi: explicit arrays, else jax.random.normal(step_rng) /
+ * (infill_rng) from the two threefry keys (use_threefry; the state is rows [sample_offset, +B) of a global array of
+ * tf_n_total elements), else Philox keyed by (seed, global sample index, step).  metrics_partial [B][3] receives the
+ * per-sample sums behind grad_norm / step_norm / noise_norm (:157-161); collect_out a copy of the new state. */
+typedef struct smd_langevin_io {
+  float* x;
+  const float* grad;
+  float alpha, noise_coef;
+  const float* z_in;
+  uint32_t seed_lo, seed_hi, step, sample_offset;
+  int32_t use_threefry;
+  uint32_t tf_noise_key[2], tf_infill_key[2];
+  int64_t tf_n_total;
+  const float* infill_samples;
+  const float* infill_masks;
+  const float* infill_z_in;
+  float infill_sigma;
+  float* metrics_partial;
+  float* collect_out;
+} smd_langevin_io;
+int smd_langevin_step(const smd_langevin_io* io, int B, int S, int C, void* stream);
+
 /* process-wide kernel-selection knob for benchmark A/B runs (defaults = fast paths).
  * "gemm_nt256": 1 = large Dense GEMMs use the 256x256 8-phase kernel (default), 0 = 128-wide tiles only,
  *               2 = every shape with M,N % 256 == 0 and K % 128 == 0 (tests);

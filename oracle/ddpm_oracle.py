@@ -532,6 +532,117 @@ def diffusion_dynamics(model, betas: np.ndarray, init, noises, infill=False,
     return state, collection, metrics
 
 
+# ----------------------------------------------------------------------------------
+# NCSN path ("next" row of SURVEY section 8): denoising score matching + Langevin samplers
+# ----------------------------------------------------------------------------------
+def dsm_used_sigmas(sigmas: np.ndarray, labels: np.ndarray, continuous_noise: bool, u01: Optional[np.ndarray] = None):
+    """utils/losses.py:155-161: sigmas[labels], or uniform(minval=sigmas[labels-1], maxval=sigmas[labels]) =
+    max(lo, u01 (hi - lo) + lo) in float32 (on a decreasing schedule lo > hi and the draw degenerates to lo)."""
+    sigmas = np.asarray(sigmas, dtype=np.float32)
+    labels = np.asarray(labels)
+    if not continuous_noise:
+        return sigmas[labels]
+    lo, hi = sigmas[labels - 1], sigmas[labels]
+    if u01 is None:
+        if (lo < hi).any():
+            raise ValueError("an increasing schedule makes the uniform of :156-159 a real draw: pass u01")
+        return lo
+    u01 = np.asarray(u01, dtype=np.float32)
+    return np.maximum(lo, (u01 * (hi - lo)).astype(np.float32) + lo).astype(np.float32)
+
+
+def denoising_score_matching_loss(batch, model, sigmas, labels, eps, continuous_noise=False, reduction="mean", u01=None):
+    """utils/losses.py:129-179 with the draws (labels :149-152, eps :164) passed in."""
+    B = batch.shape[0]
+    used = torch.from_numpy(dsm_used_sigmas(sigmas, labels, continuous_noise, u01)).to(batch.dtype)
+    used = used.reshape(B, *([1] * (batch.dim() - 1)))                          # :162-163
+    noise = eps * used                                                          # :164
+    perturbed = batch + noise                                                   # :165
+    target = -1 / (used ** 2) * noise                                           # :166
+    scores = model(perturbed, used)                                             # :167
+    assert target.shape == batch.shape and scores.shape == batch.shape
+    target, scores = target.reshape(B, -1), scores.reshape(B, -1)
+    loss = 0.5 * ((scores - target) ** 2).sum(dim=-1) * used.reshape(B) ** 2    # :175-177
+    return reduce_fn(loss, reduction)
+
+
+def ald_collection_slot(collection_idx: np.ndarray, image_idx: int) -> int:
+    """utils/ebm_utils.py:149-156: idx = sum(arange(n) * in1d(collection_idx, image_idx)) + 1 when any entry matches
+    (matching positions ADD UP when linspace repeats a value, i.e. when len(sigmas) * T < 100), else -1."""
+    hit = np.nonzero(np.asarray(collection_idx) == image_idx)[0]
+    return int(hit.sum()) + 1 if len(hit) else -1
+
+
+def annealed_langevin_dynamics(model, sigmas, init, epsilon, T, denoise, noises, infill=False, infill_samples=None,
+                               infill_masks=None, infill_noises=None):
+    """utils/ebm_utils.py:89-198.  ``noises(sigma_i, i)`` / ``infill_noises(sigma_i, i)`` return the N(0,1) draws of
+    :141-142 / :137-138.  Returns (state, collection (100 + 1 + denoise, ...), metrics (4, L, T))."""
+    dt = init.dtype
+    sig = [float(np.float32(s)) for s in np.asarray(sigmas)]
+    L = len(sig)
+    assert L >= 2
+    if not infill:
+        infill_samples, infill_masks = torch.zeros_like(init), torch.zeros_like(init)     # :122-124
+    n_coll = 100 + 1 + int(bool(denoise))
+    collection = torch.zeros((n_coll, *init.shape), dtype=dt)
+    collection[0] = init * (1 - infill_masks) + infill_samples * infill_masks              # :127-129
+    cidx = np.linspace(1, L * T, 100).astype(np.int32)                                      # :130-132
+    metrics = torch.zeros((4, L, T), dtype=dt)
+    state = init
+    B = init.shape[0]
+    for si in range(L):
+        sigma = sig[si]
+        alpha = float(np.float32(epsilon) * (np.float32(sigma) / np.float32(sig[-1])) ** 2)  # :168
+        for i in range(T):
+            y = infill_samples + sigma * (infill_noises(si, i) if infill else torch.zeros_like(init))    # :137-138
+            cond = torch.full((B, *([1] * (init.dim() - 1))), sigma, dtype=dt)
+            grad = model(state, cond)                                                        # :140
+            noise = math.sqrt(2 * alpha) * noises(si, i)                                     # :141-142
+            nxt = state + alpha * grad + noise                                               # :143
+            nxt = nxt * (1 - infill_masks) + y * infill_masks                                # :146
+            slot = ald_collection_slot(cidx, si * T + i + 1)                                 # :149-156
+            if 0 < slot < n_coll:
+                collection[slot] = nxt
+            metrics[0, si, i] = _norm_metric(grad)                                           # :159-163
+            metrics[1, si, i] = _norm_metric(alpha * grad)
+            metrics[2, si, i] = alpha
+            metrics[3, si, i] = _norm_metric(noise)
+            state = nxt
+    if denoise:                                                                              # :189-192
+        cond = torch.full((B, *([1] * (init.dim() - 1))), sig[-1], dtype=dt)
+        state = state + sig[-1] ** 2 * model(state, cond)
+        collection[-1] = state
+    return state, collection, metrics
+
+
+def consistent_langevin_dynamics(model, sigmas, init, epsilon, denoise, noises):
+    """utils/ebm_utils.py:201-271.  ``noises(i)`` = the N(0,1) draw of :241-242.  Returns (state, metrics (4, L, 1))."""
+    dt = init.dtype
+    sig = [float(np.float32(s)) for s in np.asarray(sigmas)]
+    L = len(sig)
+    assert L >= 2
+    beta = math.sqrt(1 - (1 - epsilon / sig[-1] ** 2) ** 2)                                  # :257
+    metrics = torch.zeros((4, L, 1), dtype=dt)
+    state = init
+    B = init.shape[0]
+    for i in range(L):
+        sigma = sig[i]
+        next_sigma = sig[i + 1] if i < L - 1 else 0.0                                        # :236
+        alpha = epsilon * (sigma / sig[-1]) ** 2                                             # :238
+        cond = torch.full((B, *([1] * (init.dim() - 1))), sigma, dtype=dt)
+        grad = model(state, cond)
+        noise = beta * next_sigma * noises(i)                                                # :240-241
+        metrics[0, i, 0] = _norm_metric(grad)
+        metrics[1, i, 0] = _norm_metric(alpha * grad)
+        metrics[2, i, 0] = alpha
+        metrics[3, i, 0] = _norm_metric(noise)
+        state = state + alpha * grad + noise                                                 # :242
+    if denoise:                                                                              # :264-265
+        cond = torch.full((B, *([1] * (init.dim() - 1))), sig[-1], dtype=dt)
+        state = state + sig[-1] ** 2 * model(state, cond)
+    return state, metrics
+
+
 def collate_sampling_metrics(ld_metrics):
     """utils/ebm_utils.py:408-428."""
     _, num_sigmas, num_steps = ld_metrics.shape
@@ -737,6 +848,35 @@ def jax_diffusion_loss_u01(rng, B: int) -> np.ndarray:
     first, _label_rng, _sample_rng = jax_split(rng, 3)
     _rng, noise_rng = jax_split(first)
     return jax_uniform(noise_rng, B, 0.0, 1.0)
+
+
+def jax_dsm_loss_draws(rng, batch_shape, sigmas, continuous_noise: bool = False):
+    """(labels, used_sigmas, eps) of utils/losses.py:149-164 for key ``rng``."""
+    first, label_rng, sample_rng = jax_split(rng, 3)
+    B = int(batch_shape[0])
+    labels = jax_randint(label_rng, B, int(continuous_noise), len(sigmas))
+    u01 = None
+    if continuous_noise:
+        _rng, noise_rng = jax_split(first)
+        u01 = jax_uniform(noise_rng, B, 0.0, 1.0)
+    used = dsm_used_sigmas(sigmas, labels, continuous_noise, u01)
+    eps = jax_normal(sample_rng, int(np.prod(batch_shape))).reshape(batch_shape)
+    return labels, used, eps
+
+
+def jax_langevin_keys(ld_rng, iterations: int, consistent: bool = False):
+    """Per-update keys: annealed ``rng, step_rng, infill_rng = split(rng, 3)`` (utils/ebm_utils.py:133), consistent
+    ``rng, step_rng = split(rng)`` (:233).  Returns (step_keys, infill_keys) lists (infill_keys empty when consistent)."""
+    rng = ld_rng
+    step_keys, infill_keys = [], []
+    for _ in range(iterations):
+        if consistent:
+            rng, s = jax_split(rng)
+        else:
+            rng, s, f = jax_split(rng, 3)
+            infill_keys.append(f)
+        step_keys.append(s)
+    return step_keys, infill_keys
 
 
 def jax_sampler_keys(ld_rng, T: int):

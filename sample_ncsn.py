@@ -72,6 +72,13 @@ def infill_samples(FLAGS, model, rng, samples, masks, sigmas, sample_offset=0, g
     else:
         g = torch.Generator(device=model.engine.device).manual_seed(init_rng.seed & 0x7FFFFFFFFFFFFFFF)
         init = torch.rand(samples.shape, generator=g, device=model.engine.device)
+    if FLAGS.sampling == "ald":                                             # :219-221
+        generated, collection, ld_metrics = ncsn.annealed_langevin_dynamics(
+            ld_rng, model, sigmas, init, FLAGS.ld_epsilon, FLAGS.ld_steps, FLAGS.denoise, True,
+            infill_samples=samples, infill_masks=masks, sample_offset=sample_offset, global_num_samples=global_num_samples)
+        return generated, collection, ncsn.collate_sampling_metrics(ld_metrics.cpu().numpy())
+    if FLAGS.sampling == "cas":                                             # :222-223 -> NotImplementedError (:228-229)
+        ncsn.consistent_langevin_dynamics(ld_rng, model, sigmas, init, FLAGS.ld_epsilon, FLAGS.ld_steps, FLAGS.denoise, True)
     generated, collection, ld_metrics = ncsn.diffusion_dynamics(
         ld_rng, model, sigmas, init, FLAGS.ld_epsilon, FLAGS.ld_steps, FLAGS.denoise, True,
         infill_samples=samples, infill_masks=masks, use_graph=FLAGS.graph, sample_offset=sample_offset,
@@ -105,8 +112,10 @@ def main(argv):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if rank == 0:
         log.info(FLAGS.flags_into_string())
-    if FLAGS.sampling != "ddpm":
-        raise SystemExit("this engine covers --sampling=ddpm")
+    if FLAGS.sampling not in ("ddpm", "ald", "cas"):
+        raise SystemExit(f"Unknown sampling algorithm: {FLAGS.sampling}")
+    if FLAGS.interpolate and FLAGS.sampling != "ddpm":
+        raise SystemExit("--interpolate is a DDPM mode (sample_ncsn.py:250,270 assert it)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:

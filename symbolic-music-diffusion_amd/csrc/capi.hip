@@ -87,6 +87,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
+  if (std::string(key) == "loss_kind") { e->impl.loss_kind = value ? 1 : 0; return 0; }
   if (std::string(key) == "label_min") { e->impl.label_min = value ? 1 : 0; return 0; }
   if (std::string(key) == "mlp_hs") { e->impl.mlp_hs = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
@@ -314,6 +315,19 @@ int smd_adam_clip_ema(float* params, const float* grads, float* m, float* v, flo
   a.step_ptr = step_ptr; a.norm_partial = norm_partial; a.metrics_out = metrics_out;
   int rc = launch_grad_sumsq(a, S(stream));
   return rc ? rc : launch_adam_clip_ema(a, S(stream));
+}
+int smd_langevin_step(const smd_langevin_io* io, int Bn, int Sn, int C, void* stream) {
+  SMD_ARG_CHECK(io, "langevin_step: null io");
+  LangevinStepArgs a;
+  a.x = io->x; a.grad = io->grad; a.B = Bn; a.S = Sn; a.C = C; a.alpha = io->alpha; a.noise_coef = io->noise_coef;
+  a.z_in = io->z_in; a.key = RngKey{io->seed_lo, io->seed_hi}; a.step = io->step; a.sample_offset = io->sample_offset;
+  a.use_threefry = io->use_threefry;
+  a.tf_noise_key[0] = io->tf_noise_key[0]; a.tf_noise_key[1] = io->tf_noise_key[1];
+  a.tf_infill_key[0] = io->tf_infill_key[0]; a.tf_infill_key[1] = io->tf_infill_key[1];
+  a.tf_n_total = io->tf_n_total;
+  a.infill_samples = io->infill_samples; a.infill_masks = io->infill_masks; a.infill_z_in = io->infill_z_in;
+  a.infill_sigma = io->infill_sigma; a.metrics_partial = io->metrics_partial; a.collect_out = io->collect_out;
+  return launch_langevin_step(a, S(stream));
 }
 int smd_rng_normal(float* out, int Bn, int per_sample, uint32_t lo, uint32_t hi, uint32_t stream_id, uint32_t off, void* stream) {
   return launch_fill_normal(out, Bn, per_sample, RngKey{lo, hi}, stream_id, off, S(stream));

@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
     label = a.label_min + (int)(r.x % (uint32_t)a.T);
   }
   float alpha;
-  if (a.alpha_in) {
+  if (a.dsm) {
+    alpha = 0.f;                                      // unused: x_t = x0 + sigma * eps below
+  } else if (a.alpha_in) {
     alpha = a.alpha_in[b];
   } else if (label > 0) {
     // jax-0.2.8 uniform(minval=ap[l-1], maxval=ap[l]) degenerates to minval
@@ -62,7 +64,8 @@ __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
     const float u = __uint_as_float((r.y >> 9) | 0x3F800000u) - 1.0f;
     alpha = fmaxf(lo, u * (1.0f - lo) + lo);
   }
-  const float sa = sqrtf(alpha), sb = sqrtf(1.0f - alpha);
+  // denoising score matching (utils/losses.py:163-167): perturbed = batch + used_sigma * eps, conditioned on used_sigma
+  const float sa = a.dsm ? 1.0f : sqrtf(alpha), sb = a.dsm ? a.alpha_in[b] : sqrtf(1.0f - alpha);
   const size_t base = (size_t)b * SC + e0;
   float4 eps;
   if (a.eps_in) {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
     if constexpr (!VEC4) a.eps_out[base + i] = ev[i];
   }
   if constexpr (VEC4) *reinterpret_cast<float4*>(a.eps_out + base) = eps;
-  if (g == 0) a.s_out[b] = sa;
+  if (g == 0) a.s_out[b] = a.dsm ? sb : sa;
 }
 
 template <int VEC> struct VecT;
@@ -127,9 +130,16 @@ __global__ __launch_bounds__(1024) void mse_loss_grad_kernel(const float* __rest
                                                              const float* __restrict__ eps, int S, int C, int Cp,
                                                              float inv_global_count,
                                                              float* __restrict__ loss_per_sample,
-                                                             bf16_t* __restrict__ dpred) {
+                                                             bf16_t* __restrict__ dpred,
+                                                             const float* __restrict__ dsm_sigma) {
   __shared__ float red[16];
   const int b = blockIdx.x, SC = S * C;
+  // DDPM: d = pred - eps, loss = mean d^2, dpred = 2 d / (Bg S C).  Denoising score matching (utils/losses.py:166-178):
+  // target = -eps / sigma, loss = 0.5 sum (pred - target)^2 sigma^2 = 0.5 sum (sigma pred + eps)^2; with d = sigma pred + eps
+  // the gradient of the batch MEAN is d sigma / Bg.
+  const float sg = dsm_sigma ? dsm_sigma[b] : 1.0f;
+  const float qs = dsm_sigma ? -1.0f : 1.0f;
+  const float gscale = dsm_sigma ? sg * inv_global_count * (float)SC : 2.0f * inv_global_count;
   float acc = 0.f;
   for (int e = threadIdx.x * VEC; e < SC; e += 1024 * VEC) {
     float p[VEC], q[VEC];
@@ -141,15 +151,15 @@ __global__ __launch_bounds__(1024) void mse_loss_grad_kernel(const float* __rest
       bf16x4_t o;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const float d = p[v] - q[v];
+        const float d = sg * p[v] - qs * q[v];
         acc += d * d;
-        o[v] = f2bf(2.0f * d * inv_global_count);
+        o[v] = f2bf(d * gscale);
       }
       *reinterpret_cast<bf16x4_t*>(dst) = o;
     } else {
-      const float d = p[0] - q[0];
+      const float d = sg * p[0] - qs * q[0];
       acc += d * d;
-      dst[0] = f2bf(2.0f * d * inv_global_count);
+      dst[0] = f2bf(d * gscale);
     }
   }
   acc = wave_sum(acc);
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(1024) void mse_loss_grad_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i];
-    loss_per_sample[b] = t / (float)SC;
+    loss_per_sample[b] = dsm_sigma ? 0.5f * t : t / (float)SC;
   }
 }
 
@@ -324,6 +334,61 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
 
 __global__ void advance_t_kernel(int* t_ptr) { *t_ptr -= 1; }
 
+// ------------------------------------------------------------------ Langevin update (annealed / consistent)
+// utils/ebm_utils.py:131-164 (langevin_step of annealed_langevin_dynamics) and :231-253 (consistent):
+//   next = state + alpha * grad + noise_coef * z ;  next = next (1 - mask) + (infill + infill_sigma * zi) mask
+// One workgroup per sample, a thread per column walking the sequence axis, so the per-column sums over axis 1 of the
+// metrics (:157-161) stay in registers; 2-D states (S == 1) reduce over the channel axis instead.
+__global__ __launch_bounds__(256) void langevin_step_kernel(LangevinStepArgs a) {
+  __shared__ float red[4][3];
+  const int b = blockIdx.x;
+  const uint32_t bglob = (uint32_t)b + a.sample_offset;
+  const size_t sample_base = (size_t)b * a.S * a.C;
+  const uint64_t tf_base = (uint64_t)bglob * a.S * a.C;
+  const TfKey nk{a.tf_noise_key[0], a.tf_noise_key[1]}, ik{a.tf_infill_key[0], a.tf_infill_key[1]};
+  float m_g = 0.f, m_s = 0.f, m_z = 0.f;
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float acc_g = 0.f, acc_s = 0.f, acc_z = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+      const int e = s * a.C + c;
+      const size_t idx = sample_base + e;
+      const float x = a.x[idx], g = a.grad[idx];
+      float z;
+      if (a.z_in) z = a.z_in[idx];
+      else if (a.use_threefry) z = jax_normal_from_bits(jax_bits_at(nk, tf_base + e, (uint64_t)a.tf_n_total));
+      else z = pick4(philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_Z, a.step, a.key.seed_lo, a.key.seed_hi), e & 3);
+      const float noise = a.noise_coef * z;
+      const float stp = a.alpha * g;
+      float nx = x + stp + noise;                                                  // :143 gradient ascent
+      if (a.infill_masks) {                                                         // :137-138,146
+        float zi;
+        if (a.infill_z_in) zi = a.infill_z_in[idx];
+        else if (a.use_threefry) zi = jax_normal_from_bits(jax_bits_at(ik, tf_base + e, (uint64_t)a.tf_n_total));
+        else zi = pick4(philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_INFILL, a.step, a.key.seed_lo, a.key.seed_hi), e & 3);
+        const float y = a.infill_samples[idx] + a.infill_sigma * zi;
+        const float im = a.infill_masks[idx];
+        nx = nx * (1.0f - im) + y * im;
+      }
+      acc_g += g * g; acc_s += stp * stp; acc_z += noise * noise;
+      a.x[idx] = nx;
+      if (a.collect_out) a.collect_out[idx] = nx;
+    }
+    if (a.S > 1) { m_g += sqrtf(acc_g + 1e-10f); m_s += sqrtf(acc_s + 1e-10f); m_z += sqrtf(acc_z + 1e-10f); }
+    else { m_g += acc_g; m_s += acc_s; m_z += acc_z; }
+  }
+  if (a.metrics_partial) {
+    m_g = wave_sum(m_g); m_s = wave_sum(m_s); m_z = wave_sum(m_z);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[w][0] = m_g; red[w][1] = m_s; red[w][2] = m_z; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      if (a.S == 1) v = sqrtf(v + 1e-10f);
+      a.metrics_partial[(size_t)b * 3 + threadIdx.x] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void cast_pad_bf16_kernel(const float* __restrict__ in, int rows, int cols,
                                                             bf16_t* __restrict__ out, int ld_out) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -371,6 +436,7 @@ int launch_q_sample(const QSampleArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.x0 && a.alphas_prod_ext && a.xt_bf16 && a.eps_out && a.s_out, "q_sample: null pointer");
   SMD_ARG_CHECK(a.B > 0 && a.S > 0 && a.C > 0 && a.Cp >= a.C && a.T > 0, "q_sample: bad shape");
   SMD_ARG_CHECK(a.label_min == 0 || a.label_min == 1, "q_sample: label_min=%d", a.label_min);
+  SMD_ARG_CHECK(!a.dsm || a.alpha_in, "q_sample: the score-matching form needs the per-sample used_sigmas");
   const int groups = (a.S * a.C + 3) / 4;
   const dim3 grid((groups + 255) / 256, a.B);
   if ((a.S * a.C) % 4 == 0) hipLaunchKernelGGL(q_sample_kernel<true>, grid, dim3(256), 0, st, a);
@@ -380,15 +446,15 @@ int launch_q_sample(const QSampleArgs& a, hipStream_t st) {
 }
 
 int launch_mse_loss_grad(const float* pred, const float* eps, int B, int S, int C, int Cp, float inv_global_count,
-                         float* loss_per_sample, bf16_t* dpred_bf16, hipStream_t st) {
+                         float* loss_per_sample, bf16_t* dpred_bf16, hipStream_t st, const float* dsm_sigma) {
   SMD_ARG_CHECK(pred && eps && loss_per_sample && dpred_bf16 && B > 0 && S > 0 && C > 0 && Cp >= C,
                 "mse_loss_grad: bad arguments");
   if (C % 4 == 0 && Cp % 4 == 0)
     hipLaunchKernelGGL(mse_loss_grad_kernel<4>, dim3(B), dim3(1024), 0, st, pred, eps, S, C, Cp, inv_global_count,
-                       loss_per_sample, dpred_bf16);
+                       loss_per_sample, dpred_bf16, dsm_sigma);
   else
     hipLaunchKernelGGL(mse_loss_grad_kernel<1>, dim3(B), dim3(1024), 0, st, pred, eps, S, C, Cp, inv_global_count,
-                       loss_per_sample, dpred_bf16);
+                       loss_per_sample, dpred_bf16, dsm_sigma);
   SMD_LAUNCH_CHECK();
   return 0;
 }
@@ -411,6 +477,16 @@ int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
     if (vec) hipLaunchKernelGGL((reverse_step_kernel<4, 1>), dim3(a.B), dim3(128), 0, st, a);
     else hipLaunchKernelGGL((reverse_step_kernel<1, 1>), dim3(a.B), dim3(128), 0, st, a);
   }
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_langevin_step(const LangevinStepArgs& a, hipStream_t st) {
+  SMD_ARG_CHECK(a.x && a.grad && a.B > 0 && a.S > 0 && a.C > 0, "langevin_step: bad arguments");
+  SMD_ARG_CHECK(!a.infill_masks || a.infill_samples, "langevin_step: infill needs both the samples and the masks");
+  SMD_ARG_CHECK(!a.use_threefry || (a.tf_n_total >= ((int64_t)a.sample_offset + a.B) * a.S * a.C && a.tf_n_total <= (1ll << 32)),
+                "langevin_step: tf_n_total=%lld must cover this rank's window and be <= 2^32", (long long)a.tf_n_total);
+  hipLaunchKernelGGL(langevin_step_kernel, dim3(a.B), dim3(256), 0, st, a);
   SMD_LAUNCH_CHECK();
   return 0;
 }

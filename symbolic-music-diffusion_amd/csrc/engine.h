@@ -114,6 +114,10 @@ class SmdEngine {
   // used_alpha in [alphas_prod[T], 1).  used_alphas (device, [B], may be null) overrides the label -> alpha lookup of the
   // NEXT loss_backward calls until it is reset to null.
   int label_min = 1;
+  // 0: diffusion_loss (utils/losses.py:250-308).  1: denoising_score_matching_loss (:129-179) on the same network:
+  // used_alphas then holds the per-sample used_sigmas (required), the network is conditioned on sigma, and the loss /
+  // gradient are 0.5 sum (sigma score + eps)^2 and its batch mean's derivative.
+  int loss_kind = 0;
   void set_used_alphas(const float* a) { used_alphas_ = a; }
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch

@@ -764,12 +764,13 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     q.x0 = x0; q.B = batch_; q.S = S; q.C = C; q.Cp = Cp_; q.T = d_.num_timesteps;
     q.alphas_prod_ext = alphas_prod_ext_;
     q.labels = labels; q.eps_in = eps_in; q.key = RngKey{seed_lo, seed_hi};
-    q.label_min = label_min; q.alpha_in = used_alphas_;
+    q.label_min = label_min; q.alpha_in = used_alphas_; q.dsm = loss_kind;
+    SMD_ARG_CHECK(!loss_kind || used_alphas_, "loss_backward: the score-matching loss needs set_used_alphas(used_sigmas)");
     q.step_ptr = step_ptr_; q.sample_offset = sample_offset;
     q.xt_bf16 = W.x_bf16; q.eps_out = W.eps; q.s_out = W.s;
     RC(launch_q_sample(q, st));
     RC(run_network(nullptr, st));
-    RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st));
+    RC(launch_mse_loss_grad(W.pred, W.eps, batch_, S, C, Cp_, inv_global_count, W.loss, W.dpred, st, loss_kind ? W.s : nullptr));
     if (grads_zeroed) {
       hipError_t e = hipStreamWaitEvent(st, grads_zeroed, 0);
       if (e != hipSuccess) { smd_set_error("loss_backward: %s", hipGetErrorString(e)); return (int)e; }

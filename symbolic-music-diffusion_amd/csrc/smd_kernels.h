@@ -212,6 +212,8 @@ struct QSampleArgs {
   const int* labels = nullptr;            // [B] explicit labels in [0,T] or null -> Philox
   int label_min = 1;                      // Philox labels in [label_min, label_min + T): 1 = continuous_noise, 0 = not
   const float* alpha_in = nullptr;        // [B] explicit used_alphas (utils/losses.py:283-286) or null -> from the label
+  int dsm = 0;                            // 1: denoising score matching (:163-165): alpha_in holds used_sigmas,
+                                          //    x_t = x0 + sigma * eps and s_out = sigma
   const float* eps_in = nullptr;          // explicit eps or null -> Philox
   RngKey key{0, 0};
   const uint32_t* step_ptr = nullptr;     // device step counter (RNG stream offset), may be null
@@ -225,7 +227,7 @@ int launch_q_sample(const QSampleArgs& a, hipStream_t st);
 // loss + dpred: loss_b = mean_{s,c} (eps-pred)^2 ; dpred = 2 (pred-eps) / (Bglobal*S*C) -> bf16 [B*S][Cp]
 int launch_mse_loss_grad(const float* pred, const float* eps, int B, int S, int C, int Cp,
                          float inv_global_count, float* loss_per_sample, bf16_t* dpred_bf16,
-                         hipStream_t st);
+                         hipStream_t st, const float* dsm_sigma = nullptr);   // dsm_sigma [B]: the score-matching form
 
 // fused reverse step (reference utils/ebm_utils.py:327-394)
 struct ReverseStepArgs {
@@ -255,6 +257,30 @@ struct ReverseStepArgs {
 };
 int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st);
 int launch_advance_t(int* t_ptr, hipStream_t st);   // *t_ptr -= 1
+
+// Langevin update of annealed_langevin_dynamics / consistent_langevin_dynamics (utils/ebm_utils.py:131-164, 231-253)
+struct LangevinStepArgs {
+  float* x = nullptr;                 // [B][S][C] state, updated in place
+  const float* grad = nullptr;        // [B][S][C] model(state, sigma)
+  int B = 0, S = 0, C = 0;
+  float alpha = 0.f;                  // step size
+  float noise_coef = 0.f;             // sqrt(2 alpha) (annealed) or beta * next_sigma (consistent)
+  const float* z_in = nullptr;        // explicit N(0,1) draw or null
+  RngKey key{0, 0};
+  uint32_t step = 0;                  // Philox counter word of this update
+  uint32_t sample_offset = 0;
+  int use_threefry = 0;               // jax.random.normal(step_rng / infill_rng) drawn in the kernel from the two keys below
+  uint32_t tf_noise_key[2] = {0, 0};
+  uint32_t tf_infill_key[2] = {0, 0};
+  int64_t tf_n_total = 0;
+  const float* infill_samples = nullptr;
+  const float* infill_masks = nullptr;
+  const float* infill_z_in = nullptr;
+  float infill_sigma = 0.f;           // y = infill_samples + sigma * N(0,1)
+  float* metrics_partial = nullptr;   // [B][3] (grad, step, noise): sums over c of sqrt(sum_s v^2 + 1e-10)
+  float* collect_out = nullptr;       // [B][S][C] copy of the new state or null
+};
+int launch_langevin_step(const LangevinStepArgs& a, hipStream_t st);
 
 // fp32 [rows][cols] -> bf16 [rows][ld_out] zero padded
 int launch_cast_pad_bf16(const float* in, int rows, int cols, bf16_t* out, int ld_out, hipStream_t st);

@@ -95,6 +95,7 @@ class Engine:
         self._wstate = share_params_with._wstate if share_params_with is not None else {"ver": 0}
         self._wseen = -1
         self._label_min = 1
+        self._loss_kind = 0
         self.grads = self.m = self.v = self.ema = None
         self.step_counter = None
         self.metrics = None
@@ -233,10 +234,15 @@ class Engine:
     def loss_backward(self, x0: torch.Tensor, labels: Optional[torch.Tensor] = None,
                       eps: Optional[torch.Tensor] = None, seed: int = 0, sample_offset: int = 0,
                       global_batch: Optional[int] = None, stage: int = 0, *, used_alphas: Optional[torch.Tensor] = None,
-                      continuous_noise: bool = True) -> None:
+                      continuous_noise: bool = True, objective: str = "ddpm") -> None:
         """``continuous_noise=False``: labels in [0, T) (utils/losses.py:272-275) and a real uniform used_alpha for label 0;
-        ``used_alphas`` ([B] floats) passes the draws of :283-286 explicitly."""
+        ``used_alphas`` ([B] floats) passes the draws of :283-286 explicitly.  ``objective="dsm"``: the denoising
+        score-matching loss (:129-179) on the same network; ``used_alphas`` then carries the per-sample used_sigmas."""
         B = x0.shape[0] if x0 is not None else self.batch
+        kind = {"ddpm": 0, "dsm": 1}[objective]
+        if kind != self._loss_kind:
+            _lib.check(self.L.smd_engine_set_option(self.h, b"loss_kind", kind), "set_option loss_kind")
+            self._loss_kind = kind
         lm = 1 if continuous_noise else 0
         if lm != self._label_min:
             _lib.check(self.L.smd_engine_set_option(self.h, b"label_min", lm), "set_option label_min")

@@ -167,6 +167,41 @@ def diffusion_loss_used_alphas(rng: ThreefryKey, labels: torch.Tensor, alphas_pr
     return torch.maximum(lo, u * (hi - lo) + lo).contiguous()
 
 
+def dsm_loss_draws(rng: ThreefryKey, local_shape: Sequence[int], sigmas: torch.Tensor, *, continuous_noise: bool = False,
+                   sample_offset: int = 0, global_batch: Optional[int] = None):
+    """(labels, used_sigmas, eps) of denoising_score_matching_loss (utils/losses.py:149-164): labels =
+    randint(label_rng, int(continuous_noise), len(sigmas)); used_sigmas = sigmas[labels], or with continuous noise
+    uniform(noise_rng, minval=sigmas[labels - 1], maxval=sigmas[labels]) (its minval when the schedule decreases)."""
+    _rng, label_rng, sample_rng = split(rng, 3)
+    B = int(local_shape[0])
+    gb = B if global_batch is None else int(global_batch)
+    per = int(np.prod(local_shape[1:]))
+    dev = sigmas.device
+    labels = randint(label_rng, (B,), int(continuous_noise), int(sigmas.shape[0]), dev, n_total=gb, offset=sample_offset)
+    if continuous_noise:
+        used = diffusion_loss_used_alphas(rng, labels, sigmas, sample_offset=sample_offset, global_batch=gb)
+    else:
+        used = sigmas[labels.long()].contiguous()
+    eps = normal(sample_rng, tuple(local_shape), dev, n_total=gb * per, offset=sample_offset * per)
+    return labels, used, eps
+
+
+def langevin_key_table(ld_rng: ThreefryKey, iterations: int, consistent: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-update (step_rng, infill_rng) of utils/ebm_utils.py:133 (``rng, step_rng, infill_rng = split(rng, 3)``) or, for
+    the consistent sampler, step_rng of :233 (``rng, step_rng = split(rng)``), as uint32 [iterations, 2] tables."""
+    step = np.zeros((iterations, 2), dtype=np.uint32)
+    infill = np.zeros((iterations, 2), dtype=np.uint32)
+    rng = ld_rng
+    for i in range(iterations):
+        if consistent:
+            rng, s = split(rng)
+        else:
+            rng, s, f = split(rng, 3)
+            infill[i] = (f.k0, f.k1)
+        step[i] = (s.k0, s.k1)
+    return step, infill
+
+
 def sampler_key_tables(ld_rng: ThreefryKey, iterations: int) -> Tuple[np.ndarray, np.ndarray]:
     """Per-iteration (infill_noise_rng, noise_rng) of utils/ebm_utils.py:329,342,360 as uint32 [iterations, 2]
     tables, row i = i-th call of sample_with_beta (t = T-1-i)."""

@@ -43,6 +43,14 @@ class SampleIO(C.Structure):
                 ("tf_t0", c_i32)]
 
 
+class LangevinIO(C.Structure):
+    _fields_ = [("x", c_void), ("grad", c_void), ("alpha", C.c_float), ("noise_coef", C.c_float), ("z_in", c_void),
+                ("seed_lo", c_u32), ("seed_hi", c_u32), ("step", c_u32), ("sample_offset", c_u32), ("use_threefry", c_i32),
+                ("tf_noise_key", c_u32 * 2), ("tf_infill_key", c_u32 * 2), ("tf_n_total", c_i64),
+                ("infill_samples", c_void), ("infill_masks", c_void), ("infill_z_in", c_void), ("infill_sigma", C.c_float),
+                ("metrics_partial", c_void), ("collect_out", c_void)]
+
+
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
 _SIGS = {
     "smd_last_error": (C.c_char_p, []),
@@ -118,6 +126,7 @@ _SIGS = {
     "smd_mse_fwd_bwd": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_void, c_void, c_void]),
     "smd_adam_clip_ema": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_int64, C.POINTER(TrainHyper), c_void, c_void,
                                     c_void, c_void]),
+    "smd_langevin_step": (C.c_int, [C.POINTER(LangevinIO), C.c_int, C.c_int, C.c_int, c_void]),
     "smd_rng_normal": (C.c_int, [c_void, C.c_int, C.c_int, c_u32, c_u32, c_u32, c_u32, c_void]),
     "smd_cast_pad_bf16": (C.c_int, [c_void, C.c_int, C.c_int, c_void, C.c_int, c_void]),
     "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_u32,

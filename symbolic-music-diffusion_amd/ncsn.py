@@ -188,6 +188,204 @@ def diffusion_loss(batch, model: Model, betas, rng: PRNGKey, continuous_noise=Fa
     return reduce_fn(loss, reduction)
 
 
+def _ensure_any_schedule(eng: Engine) -> None:
+    """The score-matching loss passes its noise levels per sample; the engine still wants a bound schedule table."""
+    if eng.betas is None:
+        eng.set_schedule(np.linspace(1e-6, 1e-2, eng.cfg.num_timesteps, dtype=np.float32), with_sampler=False)
+
+
+def _dsm_draws(rng, batch_shape, sigmas_t: torch.Tensor, continuous_noise: bool, sample_offset: int, global_batch: int):
+    """labels / used_sigmas / eps of utils/losses.py:149-164 for this rank's rows.  ThreefryKey: the reference's streams;
+    engine key: a torch generator seeded by it draws the GLOBAL batch's labels (so shards agree) and eps comes from Philox."""
+    if isinstance(rng, ThreefryKey):
+        return _jr.dsm_loss_draws(rng, batch_shape, sigmas_t, continuous_noise=continuous_noise, sample_offset=sample_offset,
+                                  global_batch=global_batch)
+    g = torch.Generator(device="cpu").manual_seed(rng.seed & 0x7FFFFFFFFFFFFFFF)
+    L = int(sigmas_t.shape[0])
+    lab = torch.randint(int(continuous_noise), L, (global_batch,), generator=g)[sample_offset:sample_offset + batch_shape[0]]
+    lab = lab.to(sigmas_t.device)
+    # continuous noise: uniform(minval=sigmas[l-1], maxval=sigmas[l]) returns its minval on a decreasing schedule (:156-159)
+    used = sigmas_t[(lab - 1) % L] if continuous_noise else sigmas_t[lab]
+    return lab.int(), used.contiguous(), None
+
+
+def denoising_score_matching_loss(batch, model: Model, sigmas, rng: PRNGKey, continuous_noise=False, reduction="mean", *,
+                                  labels=None, eps=None, used_sigmas=None):
+    """utils/losses.py:129-179 (forward only; trainer.train_step fuses it with the backward):
+    loss_b = 0.5 * sum((model(batch + sigma_b eps, sigma_b) + eps / sigma_b)^2) * sigma_b^2.  ``labels`` / ``eps`` /
+    ``used_sigmas`` pass the draws explicitly (parity mode).  The score network is one of the engine's architectures
+    conditioned on sigma (the reference's NCSN nets have NameErrors)."""
+    eng = model.train_engine(ema=False)
+    batch = torch.as_tensor(batch).to(eng.device, torch.float32).contiguous()
+    _ensure_any_schedule(eng)
+    eng.bind(batch.shape[0], training=True)
+    sig = torch.as_tensor(np.asarray(sigmas, dtype=np.float32)).to(eng.device)
+    e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
+    if used_sigmas is not None:
+        us = torch.as_tensor(used_sigmas).to(eng.device, torch.float32).contiguous()
+    elif labels is not None:
+        lab = torch.as_tensor(labels).to(eng.device).long()
+        us = (sig[(lab - 1) % len(sig)] if continuous_noise else sig[lab]).contiguous()
+    else:
+        _lab, us, e2 = _dsm_draws(rng, tuple(batch.shape), sig, bool(continuous_noise), 0, batch.shape[0])
+        e = e if e is not None else e2
+    eng.loss_backward(batch, None, e, seed=rng.seed, stage=3, used_alphas=us, objective="dsm")
+    loss = eng.loss_per_sample().clone()
+    return reduce_fn(loss, reduction)
+
+
+# ------------------------------------------------------------------ Langevin samplers (NCSN path)
+ALD_COLLECTION_STEPS = 100                                                        # utils/ebm_utils.py:127
+
+
+def _langevin_io(x, grad, alpha, noise_coef, rng, step, sample_offset, metrics, collect):
+    io = _lib.LangevinIO()
+    io.x, io.grad = x.data_ptr(), grad.data_ptr()
+    io.alpha, io.noise_coef = float(alpha), float(noise_coef)
+    io.seed_lo, io.seed_hi = rng.seed & 0xFFFFFFFF, (rng.seed >> 32) & 0xFFFFFFFF
+    io.step, io.sample_offset = int(step), int(sample_offset)
+    io.metrics_partial = metrics.data_ptr()
+    io.collect_out = None if collect is None else collect.data_ptr()
+    return io
+
+
+def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon, T, denoise, infill=False,
+                               infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
+                               infill_noises: Optional[Callable] = None, sample_offset: int = 0,
+                               global_num_samples: Optional[int] = None):
+    """utils/ebm_utils.py:89-198.  Returns (state, collection (100 + 1 + int(denoise), ...), ld_metrics (4, L, T)).
+
+    Per update: grad = model(state, sigma) through the engine, then ONE fused kernel (csrc/diffusion.hip
+    langevin_step_kernel) applies next = state + alpha grad + sqrt(2 alpha) z, the infill blend, the three norm metrics and
+    the collection copy.  ``noises(sigma_i, i)`` / ``infill_noises(sigma_i, i)`` supply the normals explicitly; otherwise a
+    ThreefryKey reproduces the reference's ``split(rng, 3)`` stream per update and an engine key uses Philox."""
+    eng = model.engine
+    dev = eng.device
+    sig = np.asarray(sigmas, dtype=np.float32)
+    assert len(sig) >= 2                                                            # :181
+    L, T = len(sig), int(T)
+    init = torch.as_tensor(init).to(dev, torch.float32).contiguous()
+    B = init.shape[0]
+    S, Cn = eng.S, eng.C
+    if infill:
+        inf_s = torch.as_tensor(infill_samples).to(dev, torch.float32).contiguous()
+        inf_m = torch.as_tensor(infill_masks).to(dev, torch.float32).contiguous()
+        start = init * (1 - inf_m) + inf_s * inf_m                                # :128
+    else:
+        inf_s = inf_m = None
+        start = init
+    n_coll = ALD_COLLECTION_STEPS + 1 + int(bool(denoise))
+    collection = torch.zeros((n_coll, *init.shape), dtype=torch.float32, device=dev)
+    collection[0] = start
+    cidx = np.linspace(1, L * T, ALD_COLLECTION_STEPS).astype(np.int32)            # :131-133
+    x = init.clone()
+    metrics = torch.zeros((L * T, B, 3), dtype=torch.float32, device=dev)
+    alphas = np.zeros(L, dtype=np.float32)
+    jax_mode = isinstance(rng, ThreefryKey) and noises is None
+    if jax_mode:
+        step_keys, infill_keys = _jr.langevin_key_table(rng, L * T)
+        per = int(np.prod(init.shape[1:]))
+        n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
+    zbuf = torch.zeros_like(x) if noises is not None else None
+    izbuf = torch.zeros_like(x) if (infill and infill_noises is not None) else None
+    sig_vec = torch.empty((B,), dtype=torch.float32, device=dev)
+    for si in range(L):
+        sigma = np.float32(sig[si])
+        alpha = np.float32(epsilon) * (sigma / np.float32(sig[-1])) ** 2         # :168
+        alphas[si] = alpha
+        sig_vec.fill_(float(sigma))
+        for i in range(T):
+            grad = model(x, sig_vec)                                                # :140
+            image_idx = si * T + i + 1                                              # :149-156 (duplicates add up, as upstream)
+            hit = np.nonzero(cidx == image_idx)[0]
+            slot = int(hit.sum()) + 1 if len(hit) else -1
+            k = si * T + i
+            io = _langevin_io(x, grad, alpha, np.sqrt(np.float32(2) * alpha), rng, k, sample_offset, metrics[k],
+                              collection[slot] if 0 < slot < n_coll else None)
+            if zbuf is not None:
+                zbuf.copy_(torch.as_tensor(noises(si, i)).to(dev, torch.float32))
+                io.z_in = zbuf.data_ptr()
+            if inf_m is not None:
+                io.infill_samples, io.infill_masks, io.infill_sigma = inf_s.data_ptr(), inf_m.data_ptr(), float(sigma)
+                if izbuf is not None:
+                    izbuf.copy_(torch.as_tensor(infill_noises(si, i)).to(dev, torch.float32))
+                    io.infill_z_in = izbuf.data_ptr()
+            if jax_mode:
+                io.use_threefry = 1
+                io.tf_noise_key[0], io.tf_noise_key[1] = int(step_keys[k, 0]), int(step_keys[k, 1])
+                io.tf_infill_key[0], io.tf_infill_key[1] = int(infill_keys[k, 0]), int(infill_keys[k, 1])
+                io.tf_n_total = n_glob
+            with torch.cuda.device(dev):
+                _lib.check(_lib.get_lib().smd_langevin_step(C.byref(io), B, S, Cn, torch.cuda.current_stream().cuda_stream),
+                           "langevin_step")
+    if denoise:                                                                     # :189-192
+        sig_vec.fill_(float(sig[-1]))
+        x = x + float(np.float32(sig[-1]) ** 2) * model(x, sig_vec)
+        collection[-1] = x
+    m = metrics.view(L, T, B, 3)
+    denom = float(B) if S == 1 else float(B * Cn)
+    per = m.sum(dim=2) / denom                                                      # (L, T, 3)
+    ld = torch.zeros((4, L, T), dtype=torch.float32, device=dev)
+    ld[0], ld[1], ld[3] = per[..., 0], per[..., 1], per[..., 2]
+    ld[2] = torch.from_numpy(alphas).to(dev).view(L, 1).expand(L, T)
+    return x, collection, ld
+
+
+def consistent_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon, T=None, denoise=True, infill=False,
+                                 infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
+                                 sample_offset: int = 0, global_num_samples: Optional[int] = None):
+    """utils/ebm_utils.py:201-271: one update per noise level, noise = beta * sigma_{i+1} * z.  Returns
+    (state, ld_metrics (4, L, 1)) like the reference (two values; T is a null parameter there too)."""
+    del T, infill_samples, infill_masks
+    if infill:
+        raise NotImplementedError                                                   # :228-229
+    eng = model.engine
+    dev = eng.device
+    sig = np.asarray(sigmas, dtype=np.float32)
+    assert len(sig) >= 2
+    L = len(sig)
+    x = torch.as_tensor(init).to(dev, torch.float32).contiguous().clone()
+    B, S, Cn = x.shape[0], eng.S, eng.C
+    f = np.float32
+    beta = np.sqrt(f(1) - (f(1) - f(epsilon) / (sig[-1] ** 2)) ** 2, dtype=np.float32)      # :257
+    metrics = torch.zeros((L, B, 3), dtype=torch.float32, device=dev)
+    alphas = np.zeros(L, dtype=np.float32)
+    jax_mode = isinstance(rng, ThreefryKey) and noises is None
+    if jax_mode:
+        step_keys, _ = _jr.langevin_key_table(rng, L, consistent=True)
+        per = int(np.prod(x.shape[1:]))
+        n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
+    zbuf = torch.zeros_like(x) if noises is not None else None
+    sig_vec = torch.empty((B,), dtype=torch.float32, device=dev)
+    for i in range(L):
+        sigma = f(sig[i])
+        next_sigma = f(sig[i + 1]) if i < L - 1 else f(0)                          # :236
+        alpha = f(epsilon) * (sigma / f(sig[-1])) ** 2                             # :238
+        alphas[i] = alpha
+        sig_vec.fill_(float(sigma))
+        grad = model(x, sig_vec)
+        io = _langevin_io(x, grad, alpha, beta * next_sigma, rng, i, sample_offset, metrics[i], None)
+        if zbuf is not None:
+            zbuf.copy_(torch.as_tensor(noises(i)).to(dev, torch.float32))
+            io.z_in = zbuf.data_ptr()
+        if jax_mode:
+            io.use_threefry = 1
+            io.tf_noise_key[0], io.tf_noise_key[1] = int(step_keys[i, 0]), int(step_keys[i, 1])
+            io.tf_n_total = n_glob
+        with torch.cuda.device(dev):
+            _lib.check(_lib.get_lib().smd_langevin_step(C.byref(io), B, S, Cn, torch.cuda.current_stream().cuda_stream),
+                       "langevin_step")
+    if denoise:                                                                     # :264-265
+        sig_vec.fill_(float(sig[-1]))
+        x = x + float(f(sig[-1]) ** 2) * model(x, sig_vec)
+    denom = float(B) if S == 1 else float(B * Cn)
+    per = metrics.sum(dim=1) / denom                                                # (L, 3)
+    ld = torch.zeros((4, L, 1), dtype=torch.float32, device=dev)
+    ld[0, :, 0], ld[1, :, 0], ld[3, :, 0] = per[:, 0], per[:, 1], per[:, 2]
+    ld[2, :, 0] = torch.from_numpy(alphas).to(dev)
+    return x, ld
+
+
 # ------------------------------------------------------------------ reverse sampler
 def collate_sampling_metrics(ld_metrics):
     """utils/ebm_utils.py:408-428."""
@@ -325,16 +523,36 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
 def sample(scorenet: Model, sigmas, rng: PRNGKey, sample_shape, num_samples=2400, sampling="ald", epsilon=1e-3,
            steps=100, denoise=True, *, sample_offset: int = 0, use_graph: bool = True,
            global_num_samples: Optional[int] = None):
-    """train_ncsn.py:499-551 for sampling == 'ddpm' (ald / cas need the NCSN nets that are broken
-    upstream; they are a "next" row)."""
-    if sampling != "ddpm":
-        if sampling in ("ald", "cas"):
-            raise NotImplementedError(f"sampling={sampling!r}: Langevin samplers are not on the DDPM hot path")
+    """train_ncsn.py:499-551.  'ddpm': N(0,1) init + diffusion_dynamics.  'ald' / 'cas': uniform(-sqrt(12)/2, sqrt(12)/2)
+    init (:542-547) + annealed / consistent Langevin dynamics with the score network ``scorenet``.  The reference unpacks
+    three values from every sampler although consistent_langevin_dynamics returns two (a ValueError upstream); here 'cas'
+    returns a two-entry collection [init, final state]."""
+    if sampling not in ("ddpm", "ald", "cas"):
         raise ValueError(f"Unknown sampling algorithm: {sampling}")
     init_rng, ld_rng = split(rng)                                                    # :536
     eng = scorenet.engine
     if tuple(sample_shape) != eng.cfg.sample_shape:
         raise ValueError(f"sample_shape {tuple(sample_shape)} != model shape {eng.cfg.sample_shape}")
+    if sampling != "ddpm":
+        rho = float(np.sqrt(np.float32(12)) / 2)                                     # :543
+        n_all = num_samples + sample_offset if global_num_samples is None else int(global_num_samples)
+        per = int(np.prod(sample_shape))
+        if isinstance(init_rng, ThreefryKey):
+            init = _jr.uniform(init_rng, (num_samples, *sample_shape), eng.device, -rho, rho, n_total=n_all * per,
+                               offset=sample_offset * per)
+        else:      # engine key: one seeded draw of the GLOBAL array, this rank keeps its rows
+            g = torch.Generator(device="cpu").manual_seed(init_rng.seed & 0x7FFFFFFFFFFFFFFF)
+            init = ((torch.rand((n_all, *sample_shape), generator=g) * 2 - 1) * rho)[sample_offset:sample_offset + num_samples]
+            init = init.to(eng.device)
+        if sampling == "ald":
+            generated, collection, ld = annealed_langevin_dynamics(ld_rng, scorenet, sigmas, init, epsilon, steps, denoise,
+                                                                   False, sample_offset=sample_offset,
+                                                                   global_num_samples=global_num_samples)
+        else:
+            generated, ld = consistent_langevin_dynamics(ld_rng, scorenet, sigmas, init, epsilon, steps, denoise, False,
+                                                         sample_offset=sample_offset, global_num_samples=global_num_samples)
+            collection = torch.stack([init, generated])
+        return generated, collection, collate_sampling_metrics(ld.cpu().numpy())
     eng.bind(num_samples, training=False)
     init = torch.empty((num_samples, *sample_shape), dtype=torch.float32, device=eng.device)
     if isinstance(init_rng, ThreefryKey):                                            # :539-540 N(0,1), jax stream

@@ -15,7 +15,7 @@ import torch
 
 from .engine import Engine
 from .jax_random import ThreefryKey, diffusion_loss_draws, diffusion_loss_used_alphas
-from .ncsn import Model, PRNGKey, _ensure_schedule, diffusion_loss
+from .ncsn import Model, PRNGKey, _dsm_draws, _ensure_any_schedule, _ensure_schedule, diffusion_loss
 
 
 @dataclass
@@ -75,25 +75,41 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     ``lr_interval`` instead to let the kernel evaluate the stepped schedule from its own step
     counter (learning_rate is then lr0).  ``continuous_noise`` is FLAGS.continuous_noise (:278): False draws the labels
     in [0, T) and gives label 0 its real uniform noise level (utils/losses.py:272-286).  Returns (optimizer, metrics{'loss','grad','lr'})."""
-    if objective is not diffusion_loss and getattr(objective, "__name__", "") != "diffusion_loss":
-        raise ValueError("the HIP engine implements the 'ddpm' objective (diffusion_loss) only")
+    name = getattr(objective, "__name__", "")
+    if name not in ("diffusion_loss", "denoising_score_matching_loss"):
+        raise ValueError("the HIP engine implements the 'ddpm' (diffusion_loss) and 'dsm' "
+                         "(denoising_score_matching_loss) objectives; 'ssm' needs a double backward")
     eng = optimizer.engine
     batch = torch.as_tensor(batch).to(eng.device, torch.float32).contiguous()
-    _ensure_schedule(eng, sigmas, with_sampler=False)
+    dsm = name == "denoising_score_matching_loss"
+    if dsm:
+        _ensure_any_schedule(eng)
+    else:
+        _ensure_schedule(eng, sigmas, with_sampler=False)
     eng.bind(batch.shape[0], training=True)
     lab = None if labels is None else torch.as_tensor(labels).to(eng.device, torch.int32).contiguous()
     e = None if eps is None else torch.as_tensor(eps).to(eng.device, torch.float32).contiguous()
     world = 1 if comm is None else comm.world_size
     gb = batch.shape[0] * world if global_batch is None else global_batch
     ua = None if used_alphas is None else torch.as_tensor(used_alphas).to(eng.device, torch.float32).contiguous()
-    if isinstance(rng, ThreefryKey) and lab is None and e is None:
+    if dsm:
+        # utils/losses.py:149-164: the noise level travels per sample (used_alphas carries the used_sigmas)
+        sig = torch.as_tensor(np.asarray(sigmas, dtype=np.float32)).to(eng.device)
+        if ua is None and lab is not None:
+            ua = (sig[(lab.long() - 1) % len(sig)] if continuous_noise else sig[lab.long()]).contiguous()
+        elif ua is None:
+            _lab, ua, e2 = _dsm_draws(rng, tuple(batch.shape), sig, bool(continuous_noise), sample_offset, gb)
+            e = e if e is not None else e2
+        lab = None
+    elif isinstance(rng, ThreefryKey) and lab is None and e is None:
         # the reference's own draws (utils/losses.py:271-294) for this rank's rows of the global batch
         lab, e = diffusion_loss_draws(rng, tuple(batch.shape), len(sigmas), eng.device, sample_offset=sample_offset,
                                       global_batch=gb, continuous_noise=continuous_noise)
         if not continuous_noise and ua is None:
             ua = diffusion_loss_used_alphas(rng, lab, eng._sched_tensors["ape"], sample_offset=sample_offset,
                                             global_batch=gb)
-    kw = dict(seed=rng.seed, sample_offset=sample_offset, global_batch=gb, used_alphas=ua, continuous_noise=continuous_noise)
+    kw = dict(seed=rng.seed, sample_offset=sample_offset, global_batch=gb, used_alphas=ua, continuous_noise=continuous_noise,
+              objective="dsm" if dsm else "ddpm")
     if comm is None:
         eng.loss_backward(batch, lab, e, stage=0, **kw)
     else:
@@ -114,14 +130,14 @@ def eval_step(objective, batch, model: Model, sigmas, rng: PRNGKey, continuous_n
     return objective(batch, model, sigmas, rng, continuous_noise, "sum")
 
 
-def evaluate(dataset, model: Model, sigmas, rng: PRNGKey, continuous_noise: bool = True):
+def evaluate(dataset, model: Model, sigmas, rng: PRNGKey, continuous_noise: bool = True, objective=diffusion_loss):
     """train_ncsn.py:224-257: mean per-example loss over the dataset (iterable of batches)."""
     from .ncsn import split
     count, total = 0, 0.0
     for inputs in dataset:
         count += inputs.shape[0]
         rng, eval_rng = split(rng)
-        total += float(eval_step(diffusion_loss, inputs, model, sigmas, eval_rng, continuous_noise))
+        total += float(eval_step(objective, inputs, model, sigmas, eval_rng, continuous_noise))
     return {"loss": total / max(count, 1)}
 
 

@@ -234,5 +234,5 @@ def test_sample_api_full_walk_small():
     assert len(met) == 1000 and set(met[0][0]) == {"slope", "step", "alpha", "noise"}
     hit = [k for k in range(41) if float(coll[k].abs().max()) > 0]
     assert hit == [0] + list(range(2, 41))
-    with pytest.raises(NotImplementedError):
-        N.sample(model, BETAS, N.PRNGKey(1), (32, 42), num_samples=4, sampling="ald")
+    with pytest.raises(ValueError):
+        N.sample(model, BETAS, N.PRNGKey(1), (32, 42), num_samples=4, sampling="hmc")

@@ -88,6 +88,8 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
     ema = train_utils.EMAHelper(FLAGS.mu, optimizer.engine.ema if FLAGS.ema else model.params.clone(),
                                 fused=FLAGS.ema)                                  # :336 (untouched init when --ema=False)
 
+    # :345-352 (ssm needs a second backward through the network and is a toy-only objective upstream)
+    objective = {"ddpm": ncsn.diffusion_loss, "dsm": ncsn.denoising_score_matching_loss}[FLAGS.loss]
     sampling_step = -1
     for epoch in range(FLAGS.epochs):
         start_time = time.time()
@@ -96,7 +98,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
             global_step = step + epoch * train_batches.examples                   # :359
             # the stepped LR schedule (:340-342) is evaluated on the device from the update counter
             optimizer, train_metrics = train_step(
-                ncsn.diffusion_loss, batch, optimizer, sigmas, train_rng, FLAGS.learning_rate,
+                objective, batch, optimizer, sigmas, train_rng, FLAGS.learning_rate,
                 grad_clip=FLAGS.grad_clip, mu=FLAGS.mu, comm=comm, lr_gamma=FLAGS.lr_gamma,
                 lr_interval=FLAGS.lr_schedule_interval, sample_offset=rank * FLAGS.batch_size,
                 global_batch=FLAGS.batch_size * world, continuous_noise=FLAGS.continuous_noise)
@@ -115,7 +117,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
                 sampling_step += 1
                 rng, eval_rng = ncsn.split(rng)
                 if rank == 0:
-                    eval_metrics = evaluate(valid_batches, optimizer.target, sigmas, eval_rng, FLAGS.continuous_noise)
+                    eval_metrics = evaluate(valid_batches, optimizer.target, sigmas, eval_rng, FLAGS.continuous_noise, objective)
                     train_utils.log_metrics(eval_metrics, global_step, train_batches.examples * FLAGS.epochs,
                                             summary_writer=eval_writer, verbose=verbose)
                     improved, early_stop = early_stop.update(eval_metrics["loss"])            # :393
@@ -165,8 +167,8 @@ def main(argv):
     if rank == 0:
         log.info(FLAGS.flags_into_string())
         log.info("Platform: gfx950 HIP engine (smd_amd %s)", smd_amd.__version__)
-    if FLAGS.loss != "ddpm" or FLAGS.sampling != "ddpm":
-        raise SystemExit("this engine covers the DDPM path: use --loss=ddpm --sampling=ddpm (configs/ddpm-*.cfg)")
+    if FLAGS.loss not in ("ddpm", "dsm") or FLAGS.sampling not in ("ddpm", "ald", "cas"):
+        raise SystemExit("this engine covers --loss=ddpm|dsm and --sampling=ddpm|ald|cas (ssm needs a double backward)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
