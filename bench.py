@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: OCP e4m3 operands with per-row E8M0 scales for the DenseResBlock forward GEMMs (BASELINE config 5)")
+    ap.add_argument("--dp-buckets", type=int, default=1, help="N > 1 GPUs: chunks per gradient all-reduce stage (GradComm)")
+    ap.add_argument("--dp-payload", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1 GPUs: wire format of the gradient all-reduce (bf16 halves the xGMI bytes; off by default)")
     ap.add_argument("--no-roofline-microbench", action="store_true",
                     help="skip the back-to-back launches of the dominant kernel (profiling runs: the trace then holds the timed loops only)")
     return ap.parse_args()
@@ -137,7 +140,7 @@ def main():
     model = N.Model(cfg, dev, seed=0)
     betas = S.create_noise_schedule(1e-6, 0.01, 1000, "linear")
     B = a.batch
-    comm = GradComm() if world > 1 else None
+    comm = GradComm(buckets=a.dp_buckets, payload=a.dp_payload) if world > 1 else None
     if comm is not None:
         comm.broadcast_params(model.params)
         model.engine.refresh_weights()

@@ -257,6 +257,23 @@ def _dp_worker(rank, world, port, tmp):
     comm.reduce_async(mine[:head])
     comm.wait()
     assert torch.allclose(mine, full, rtol=1e-10, atol=1e-14), float((mine - full).abs().max())
+    # bucketed (3 chunks per stage) and bf16-on-the-wire variants of the same exchange
+    again = grads(slice(rank * half, (rank + 1) * half)).float().clone()
+    chunked = GradComm(buckets=3)
+    assert len(chunked._chunks(again[head:])) == 3 and sum(c.numel() for c in chunked._chunks(again[head:])) == again.numel() - head
+    chunked.reduce_async(again[head:])
+    chunked.reduce_async(again[:head])
+    chunked.wait()
+    assert torch.allclose(again.double(), full, rtol=1e-5, atol=1e-9)
+    lossy = grads(slice(rank * half, (rank + 1) * half)).float().clone()
+    half_wire = GradComm(buckets=2, payload="bf16")
+    half_wire.reduce_async(lossy[head:])
+    half_wire.reduce_async(lossy[:head])
+    half_wire.wait()
+    err = float((lossy.double() - full).norm() / full.norm())
+    assert lossy.dtype == torch.float32 and 1e-5 < err < 8e-3, err          # bf16 rounding of two addends and of their sum
+    with pytest.raises(ValueError):
+        GradComm(payload="fp16")
     flat = torch.full((10,), float(rank))
     comm.broadcast_params(flat)
     assert float(flat.sum()) == 0.0
