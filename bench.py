@@ -290,6 +290,21 @@ def main():
 
         ms = timed(call_b)
         ms_r = timed(call_r)
+        ms8 = None
+        if a.dtype == "fp8":
+            # the e4m3 form of the same GEMM (v_mfma_scale_f32_32x32x64_f8f6f4, per-row E8M0 scales): what this run's engine
+            # launches for the DenseResBlock FORWARD GEMMs; its backward GEMMs are the bf16 kernel timed above
+            q8 = [torch.empty(R, M, dtype=torch.uint8, device=dev) for _ in range(NSET)]
+            s8 = [torch.empty(R, dtype=torch.int32, device=dev) for _ in range(NSET)]
+            w8, ws8 = torch.empty(M, M, dtype=torch.uint8, device=dev), torch.empty(M, dtype=torch.int32, device=dev)
+            for i in range(NSET):
+                lib.check(L.smd_quantize_rows_e4m3(As[i].data_ptr(), M, R, M, q8[i].data_ptr(), s8[i].data_ptr(), st))
+            lib.check(L.smd_quantize_rows_e4m3(Wt.data_ptr(), M, M, M, w8.data_ptr(), ws8.data_ptr(), st))
+
+            def call_8(i):
+                lib.check(L.smd_gemm_e4m3_nt(q8[i % NSET].data_ptr(), M, s8[i % NSET].data_ptr(), w8.data_ptr(), M, ws8.data_ptr(),
+                                             R, M, M, bias.data_ptr(), None, 0, None, 0, outs[i % NSET].data_ptr(), M, st))
+            ms8 = timed(call_8)
         tf = 2.0 * R * M * M / (ms * 1e-3) / 1e12
         # HBM-side bytes per launch of this kernel: PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
         # are collected by tools/collect_profiles.sh and committed as profiles/pmc_gemm_nt256.json (corrected as
@@ -311,6 +326,13 @@ def main():
                 "traffic_note": "bytes per launch at L2's memory side from committed rocprofv3 PMC passes "
                                 "(profiles/pmc_gemm_nt256.json); algorithmic bytes = 75.5e6",
                 **step_fracs}
+        if ms8 is not None:
+            tf8 = 2.0 * R * M * M / (ms8 * 1e-3) / 1e12
+            roof["e4m3_form"] = {"kernel": "gemm_nt256_kernel<0, true> (v_mfma_scale_f32_32x32x64_f8f6f4, per-row E8M0 scales)",
+                                 "achieved": round(tf8, 1), "peak": 5000.0, "unit": "TFLOP/s", "frac": round(tf8 / 5000.0, 4),
+                                 "avg_launch_ms": round(ms8, 5),
+                                 "note": "the DenseResBlock forward GEMMs of this run; its backward GEMMs are the bf16 kernel of "
+                                         "the enclosing object"}
         # the clock-limited ceiling of this box on the same instruction with random operands and NO data movement
         # (tools/mfma_peak.hip; MI355X_MICROARCH.md "DVFS give-back"): context for `frac`, not a replacement for `peak`
         probe = os.path.join(ROOT, "tools", "mfma_peak")

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 1
+#define SMD_ABI_VERSION 2   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries */
 
 typedef uint16_t smd_bf16;
 typedef struct smd_engine smd_engine;

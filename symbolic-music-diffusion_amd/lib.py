@@ -51,6 +51,8 @@ class LangevinIO(C.Structure):
                 ("metrics_partial", c_void), ("collect_out", c_void)]
 
 
+ABI_VERSION = 2          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
+
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
 _SIGS = {
     "smd_last_error": (C.c_char_p, []),
@@ -157,13 +159,16 @@ def get_lib() -> C.CDLL:
                 raise RuntimeError(
                     f"libsmd_hip.so is missing and could not be built ({e}). The HIP extension is "
                     "mandatory: there is no CPU fallback. Run `python -m smd_amd.build`.") from e
+    # torch first: its bundled libamdhip64 must be the HIP runtime of the process.  Loading the library before torch pulls
+    # in /opt/rocm's runtime under the same SONAME instead, and the first launch then fails with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)   # AttributeError here = the .so is older than the header
         fn.restype = res
         fn.argtypes = args
-    if lib.smd_abi_version() != 1:
-        raise RuntimeError(f"libsmd_hip.so ABI {lib.smd_abi_version()} != 1; rebuild")
+    if lib.smd_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libsmd_hip.so ABI {lib.smd_abi_version()} != {ABI_VERSION}; rebuild")
     _LIB = lib
     return lib
 

@@ -79,6 +79,8 @@ class Model:
         if share_params_with is None and seed is not None:
             self.engine.init_params(seed)
         self._train_engine: Optional[Engine] = None
+        from . import ops as _ops                      # registers torch.ops.smd_amd.*
+        self._op_id = _ops.register_engine(self.engine)
 
     @property
     def params(self) -> torch.Tensor:
@@ -91,7 +93,8 @@ class Model:
         x = torch.as_tensor(x)
         cond = torch.as_tensor(cond)
         assert x.shape[0] == cond.shape[0], (x.shape, cond.shape)           # models/ncsn.py:32,50
-        return self.engine.forward(x, cond)
+        dev = self.engine.device
+        return torch.ops.smd_amd.eps_forward(x.to(dev, torch.float32), cond.to(dev, torch.float32), self._op_id)
 
     def train_engine(self, ema: bool) -> Engine:
         if self._train_engine is None:

@@ -104,8 +104,8 @@ def test_train_step_consumes_the_reference_draws():
     rng = J.PRNGKey(11)
     labels, eps = O.jax_diffusion_loss_draws(okey(rng), (B, *shape), 1000)
     assert labels.min() >= 1 and labels.max() <= 1000
-    a = N.diffusion_loss(x0, model, BETAS, rng, reduction="none").cpu()
-    b = N.diffusion_loss(x0, model, BETAS, N.PRNGKey(0), reduction="none", labels=labels, eps=eps).cpu()
+    a = N.diffusion_loss(x0, model, BETAS, rng, True, "none").cpu()                 # FLAGS.continuous_noise default (:52)
+    b = N.diffusion_loss(x0, model, BETAS, N.PRNGKey(0), True, "none", labels=labels, eps=eps).cpu()
     assert torch.allclose(a, b, rtol=2e-5, atol=1e-7)
     # the draws themselves, incl. the sharded window
     lab_d, eps_d = J.diffusion_loss_draws(rng, (B, *shape), 1000, "cuda:0")

@@ -240,3 +240,44 @@ def test_mse_and_adam_entries_match_the_oracle(L):
           f"norm {float(metrics[0]):.5f} vs {float(torch.sqrt((gr * gr).sum())):.5f}")
     assert rel(wd, params["w"]) < 1e-6 and rel(e, ema["w"]) < 1e-6 and int(step) == 3
     assert abs(float(metrics[0]) - float(torch.sqrt((gr * gr).sum()))) < 1e-4
+
+
+def test_torch_custom_ops_run_the_c_abi(L):
+    """torch.ops.smd_amd.*: the same kernels reached as PyTorch custom ops (device tensors, current stream)."""
+    import smd_amd.ops as ops
+    ocfg, p, model = _model(42, "TransformerDDPM")
+    g = torch.Generator().manual_seed(12)
+    x = torch.clamp(0.25 * torch.randn(4, 32, 42, generator=g), -1, 1).cuda()
+    s = (0.1 + 0.9 * torch.rand(4, 1, 1, generator=g)).cuda()
+    with torch.no_grad():
+        ref = O.make_model(p, ocfg)(x.double().cpu(), s.double().cpu())
+    out = torch.ops.smd_amd.eps_forward(x, s, ops.register_engine(model.engine))
+    assert rel(out, ref) < 1e-2 and torch.equal(out, model(x, s))            # Model.__call__ is this op
+    a = torch.randn(256, 128, generator=g).to(torch.bfloat16).cuda()
+    bt = (0.05 * torch.randn(384, 128, generator=g)).to(torch.bfloat16).cuda()
+    bias = torch.randn(384, generator=g).cuda()
+    c = torch.ops.smd_amd.gemm_bf16_nt(a, bt, bias)
+    assert rel(c.float(), a.double() @ bt.double().t() + bias.double()) < 4e-3
+    labels = torch.randint(1, T + 1, (4,), generator=g).int().cuda()
+    eps = torch.randn(4, 32, 42, generator=g).cuda()
+    xt, lvl = torch.ops.smd_amd.q_sample(x, torch.from_numpy(APE).cuda(), labels, eps)
+    al = torch.from_numpy(O.used_alphas_from_labels(BETAS, labels.cpu().numpy())).cuda().view(4, 1, 1)
+    assert rel(xt.float().view(4, 32, 42), torch.sqrt(al) * x + torch.sqrt(1 - al) * eps) < 3e-3
+    assert torch.allclose(lvl, torch.sqrt(al).flatten(), rtol=1e-6)
+    coef = torch.from_numpy(O_coef_table()).cuda()
+    t = torch.tensor([500], dtype=torch.int32, device="cuda")
+    z = torch.randn(4, 32, 42, generator=g).cuda()
+    x2 = x.clone()
+    torch.ops.smd_amd.ddpm_reverse_step_(x2, out, coef, t, z)
+    torch.cuda.synchronize()
+    co = O.reverse_coefficients(BETAS)
+    recon = torch.clamp(float(co["sqrt_recip"][500]) * x - float(co["sqrt_m1"][500]) * out, -1, 1)
+    want = float(co["mu1"][500]) * recon + float(co["mu2"][500]) * x + float(co["sigma"][500]) * z
+    assert rel(x2, want) < 1e-5
+    with pytest.raises(RuntimeError, match="GPU only"):
+        torch.ops.smd_amd.eps_forward(x.cpu(), s.cpu(), ops.register_engine(model.engine))
+
+
+def O_coef_table():
+    import smd_amd.schedule as S
+    return S.reverse_coefficient_table(BETAS)

@@ -291,3 +291,24 @@ def test_data_parallel_gradient_exchange_gloo(tmp_path):
     s.close()
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_custom_ops_are_registered_and_have_no_cpu_path():
+    """north_star: 'Python host code calling hand-written HIP kernels through PyTorch-ROCm custom ops (C-ABI)'."""
+    import smd_amd.ops as ops  # noqa: F401
+    for name in ("eps_forward", "gemm_bf16_nt", "ddpm_reverse_step_", "q_sample"):
+        assert hasattr(torch.ops.smd_amd, name)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        torch.ops.smd_amd.gemm_bf16_nt(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16),
+                                       torch.zeros(64))
+    # shape inference without running anything (fake tensors)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        a = torch.empty(256, 128, dtype=torch.bfloat16)
+        out = torch.ops.smd_amd.gemm_bf16_nt(a, torch.empty(512, 128, dtype=torch.bfloat16), torch.empty(512))
+        assert tuple(out.shape) == (256, 512) and out.dtype == torch.bfloat16
+        e = torch.ops.smd_amd.eps_forward(torch.empty(4, 32, 512), torch.empty(4, 1, 1), 0)
+        assert tuple(e.shape) == (4, 32, 512)
+        xt, s = torch.ops.smd_amd.q_sample(torch.empty(4, 32, 42), torch.empty(1001), torch.empty(4, dtype=torch.int32),
+                                           torch.empty(4, 32, 42))
+        assert tuple(xt.shape) == (128, 42) and tuple(s.shape) == (4,)
