@@ -416,6 +416,27 @@ int smd_tn_pad_bytes(int static_lds_bytes) {
   return pad > 0 ? pad : 0;
 }
 
+// Split-K factor of a 128x128-tile launch.  With CU-exclusive workgroups (tn_exclusive_cu) a launch runs in whole rounds of
+// 256 workgroups, so 36 tiles x 15 splits = 540 workgroups (the old "about 512" rule) took THREE rounds of 9 K-tiles;
+// 7 splits = 252 workgroups take one round of 19.  Cost in K-tile units: rounds x (K-tiles per split + a fixed prologue /
+// slab-epilogue share) + the slab traffic the split adds; the smallest wins, ties go to fewer splits.
+static int smd_tn_pick_split(int tiles, int total_kt, int max_split) {
+  if (!smd_tuning_get("tn_split_model")) {
+    int ns = (512 + tiles - 1) / tiles;
+    return ns < 1 ? 1 : (ns > max_split ? max_split : ns);
+  }
+  const int per_round = smd_tuning_get("tn_exclusive_cu") ? 256 : 512;
+  int best = 1;
+  float best_cost = 1e30f;
+  for (int ns = 1; ns <= max_split && ns <= total_kt; ++ns) {
+    const int per = (total_kt + ns - 1) / ns;
+    const int rounds = (tiles * ns + per_round - 1) / per_round;
+    const float cost = (float)rounds * ((float)per + 5.0f) + (ns > 1 ? 0.35f * (float)ns : 0.0f);
+    if (cost < best_cost - 1e-3f) { best_cost = cost; best = ns; }
+  }
+  return best;
+}
+
 size_t gemm_tn_slab_elems() { return (size_t)4 * 2048 * 2048 + (size_t)1024 * 1024; }
 
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
@@ -437,7 +458,7 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     int target = smd_tuning_get("tn128_target_wgs");
     if (target == 512 && tiles <= 16) target = 256;
     if (tiles < target && t.slab && t.ldo == t.N) {
-      nsplit = (target + tiles - 1) / tiles;
+      nsplit = smd_tuning_get("tn_split_model") ? smd_tn_pick_split(tiles, total_kt, 32) : (target + tiles - 1) / tiles;
       if (nsplit > 32) nsplit = 32;
       if (nsplit > total_kt) nsplit = total_kt;
       const size_t cap = t.slab_elems / stride;
@@ -509,7 +530,7 @@ int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st) {
       slab_per_split += ((size_t)t.Kd * t.N + t.N + 3) / 4 * 4;
     }
     ga.tile_start[cnt] = tiles;
-    int nsplit = (512 + tiles - 1) / tiles;
+    int nsplit = smd_tn_pick_split(tiles, total_kt, 32);
     if (nsplit > 32) nsplit = 32;
     if (nsplit > total_kt) nsplit = total_kt;
     if ((size_t)nsplit * slab_per_split > t0.slab_elems) nsplit = (int)(t0.slab_elems / slab_per_split);

@@ -12,12 +12,17 @@ cd /tmp; export TMPDIR=/tmp
 python $R/bench.py --steps 30 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o t -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2> $OUT/${TAG}_kt.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt/t_results.db 12 > $OUT/${TAG}_bench_kernel_trace.txt
-# per-mode traces with undistorted per-kernel times: train on ONE stream, sample step eager
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train -o t -- python $R/bench.py --mode train --side-wgrad 0 --steps 10 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2> $OUT/${TAG}_kt_train.err
+# per-mode traces with undistorted per-kernel times: train on ONE stream, sample step eager; the roofline microbench
+# (104 extra launches of the dominant kernel) is left out of these so that calls/step and the shares are the step's own
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train -o t -- python $R/bench.py --mode train --side-wgrad 0 --steps 10 --warmup 2 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_train.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt_train/t_results.db 12 > $OUT/${TAG}_train_single_stream_kernel_trace.txt
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_sample -o t -- python $R/bench.py --mode sample --steps 10 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2> $OUT/${TAG}_kt_sample.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_sample -o t -- python $R/bench.py --mode sample --steps 10 --warmup 2 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_sample.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt_sample/t_results.db 12 > $OUT/${TAG}_sample_kernel_trace.txt
-rm -rf $OUT/${TAG}_kt_train $OUT/${TAG}_kt_sample
+# the default two-stream train step without the microbench (critical-path analysis: tools/stream_busy.py)
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train2 -o t -- python $R/bench.py --mode train --steps 10 --warmup 2 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_train2.err
+python $R/tools/prof_summary.py $OUT/${TAG}_kt_train2/t_results.db 12 > $OUT/${TAG}_train_two_stream_kernel_trace.txt
+python $R/tools/stream_busy.py $OUT/${TAG}_kt_train2/t_results.db > $OUT/${TAG}_train_stream_busy.txt
+rm -rf $OUT/${TAG}_kt_train $OUT/${TAG}_kt_sample $OUT/${TAG}_kt_train2
 for P in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   N=$(echo $P | cut -d" " -f1)
