@@ -817,9 +817,10 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
           bf16x4_t u4, d4;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float zz = z[e] + bb[e];
-            u4[e] = f2bf(geluf_(zz));
-            d4[e] = f2bf(du[e] * gelu_gradf_(zz));
+            float gz, dgz;
+            gelu_fwd_grad_(z[e] + bb[e], gz, dgz);
+            u4[e] = f2bf(gz);
+            d4[e] = f2bf(du[e] * dgz);
           }
           const int piece = ht * 2 + (g >> 1);
           const int off = (s * 32 + tok) * 64 + ((piece ^ tswz) << 4) + (g & 1) * 8;

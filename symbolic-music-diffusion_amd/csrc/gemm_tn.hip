@@ -68,6 +68,37 @@ __device__ __forceinline__ void tr_read_kstep(unsigned a0, unsigned a1, unsigned
       : "memory");
 }
 
+// The same eight reads WITHOUT the wait, and the wait as a statement of its own that names the registers it releases
+// ("+v": later uses of the fragments are ordered behind it, and the asm stays where it is written): the reads of k-step
+// k+1 are issued before the MFMAs of k-step k, so a one-wave-per-SIMD workgroup (CU-exclusive wgrads) no longer sits
+// through an LDS round trip in front of every four MFMAs.  LDS reads return in order: with the next k-step's eight
+// reads queued behind them, lgkmcnt(8) means "this k-step's fragments have arrived".
+template <int KOFF>
+__device__ __forceinline__ void tr_issue_kstep(unsigned a0, unsigned a1, unsigned b0, unsigned b1,
+                                               Frag8 (&af)[2], Frag8 (&bfr)[2]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13"
+      : "=&v"(af[0].h[0]), "=&v"(af[0].h[1]), "=&v"(af[1].h[0]), "=&v"(af[1].h[1]),
+        "=&v"(bfr[0].h[0]), "=&v"(bfr[0].h[1]), "=&v"(bfr[1].h[0]), "=&v"(bfr[1].h[1])
+      : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "i"(KOFF), "i"(KOFF + 1024)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait_kstep(Frag8 (&af)[2], Frag8 (&bfr)[2]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(af[0].h[0]), "+v"(af[0].h[1]), "+v"(af[1].h[0]), "+v"(af[1].h[1]),
+                 "+v"(bfr[0].h[0]), "+v"(bfr[0].h[1]), "+v"(bfr[1].h[0]), "+v"(bfr[1].h[1])
+               : "i"(N)
+               : "memory");
+}
+
 template <int... Es> struct IntSeq {};
 typedef IntSeq<0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15> Seq16;
 // 32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -195,22 +226,32 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const unsigned tb = lds_base + buf * BUF_BYTES + m_lane * 256;
-    Frag8 af[2], bfr[2];
-#define SMD_TN_KSTEP(KOFF)                                                                      \
-    tr_read_kstep<KOFF>(tb + a_col[0], tb + a_col[1], tb + b_col[0], tb + b_col[1], af, bfr);   \
+    Frag8 af[2][2], bfr[2][2];       // two k-steps of fragments: one being multiplied, the next one arriving
+#define SMD_TN_MMA(S)                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                               \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i].v, bfr[j].v, acc[i][j], 0, 0, 0); \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[S][i].v, bfr[S][j].v, acc[i][j], 0, 0, 0); \
     if (do_bias) {                                                                              \
       _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
-        acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[j].v, acc_b[j], 0, 0, 0);  \
-    }
-    SMD_TN_KSTEP(0)
-    SMD_TN_KSTEP(4096)
-    SMD_TN_KSTEP(8192)
-    SMD_TN_KSTEP(12288)
-#undef SMD_TN_KSTEP
+        acc_b[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bfr[S][j].v, acc_b[j], 0, 0, 0); \
+    }                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);
+#define SMD_TN_ISSUE(KOFF, S) tr_issue_kstep<KOFF>(tb + a_col[0], tb + a_col[1], tb + b_col[0], tb + b_col[1], af[S], bfr[S])
+    SMD_TN_ISSUE(0, 0);
+    SMD_TN_ISSUE(4096, 1);
+    tr_wait_kstep<8>(af[0], bfr[0]);
+    SMD_TN_MMA(0)
+    SMD_TN_ISSUE(8192, 0);
+    tr_wait_kstep<8>(af[1], bfr[1]);
+    SMD_TN_MMA(1)
+    SMD_TN_ISSUE(12288, 1);
+    tr_wait_kstep<8>(af[0], bfr[0]);
+    SMD_TN_MMA(0)
+    tr_wait_kstep<0>(af[1], bfr[1]);
+    SMD_TN_MMA(1)
+#undef SMD_TN_MMA
+#undef SMD_TN_ISSUE
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     buf = buf + 1 == NS ? 0 : buf + 1;

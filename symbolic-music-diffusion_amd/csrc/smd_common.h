@@ -46,7 +46,8 @@ __device__ __forceinline__ int smd_clamp_t(int t) { return t < 0 ? 0 : t; }
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the FiLM LayerNorms evaluate this for 16.8 M elements each
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float swish_gradf_(float x) {
   float s = sigmoidf_(x);
@@ -71,6 +72,21 @@ __device__ __forceinline__ float gelu_gradf_(float x) {
   float t = tanhf_(u);
   float du = k0 * (1.0f + 3.0f * k1 * x * x);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+// gelu(x) AND gelu'(x) from ONE exp2 + ONE rcp (the recompute backward evaluates both for every hidden activation:
+// 16.8 M per encoder layer at B = 256, VALU-bound).  s = 1 / (1 + exp(-2u)) = 0.5 (1 + tanh u):
+//   gelu = x s   (the same expression, bit for bit, as geluf_)      gelu' = s + 2 x s (1 - s) du/dx,  du/dx = k0 (1 + 3 k1 x^2)
+// exp2 overflowing to +inf for very negative x gives s = 0, gelu = -0, gelu' = 0; underflow for large x gives s = 1, gelu' = 1.
+__device__ __forceinline__ void gelu_fwd_grad_(float x, float& g, float& dg) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float A = -2.0f * k0 * 1.4426950408889634f, Bc = A * k1;
+  const float x2 = x * x;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(Bc, x2, A));
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);
+  g = x * s;
+  const float xd = x * fmaf(6.0f * k0 * k1, x2, 2.0f * k0);
+  dg = fmaf(xd, s * (1.0f - s), s);
 }
 
 // ---- OCP e4m3 with a per-row power-of-two scale: e = floor(log2(amax)) - 8 puts amax * 2^-e into [256, 512), clamped to
