@@ -120,6 +120,7 @@ class SmdEngine {
   int loss_kind = 0;
   void set_used_alphas(const float* a) { used_alphas_ = a; }
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
+  int film_side_fwd = 1;   // training: FiLM generators (forward) and their backward chain run on the side stream
   int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
                                                               // layer as soon as its backward is enqueued (+4.6 % train), 1 = all at

@@ -414,6 +414,30 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
   SMD_ARG_CHECK(!(tr && t_ptr), "run_network: table-driven FiLM is inference only");
   SMD_ARG_CHECK(!t_ptr || film_tables_, "run_network: sampler tables not bound");
 
+  // Training: the FiLM generators of all blocks depend on the noise levels only and are three launch-latency-bound GEMMs
+  // of 256 rows per block (9 us each for a few MFLOP).  With the side stream on they run THERE, underneath the encoder
+  // layers, and the first DenseResBlock waits for them (film_side_fwd; the inference sampler reads tables instead).
+  hipEvent_t film_ready = nullptr;
+  if (tr && !t_ptr && film_side_fwd && side_wgrad && side_ && d_.arch == 0) {
+    RC(launch_noise_embed(W.s, B, F, W.emb, F, st));
+    hipEvent_t ev = take_event();
+    film_ready = take_event();
+    SMD_ARG_CHECK(ev && film_ready, "run_network: cannot create an event");
+    hipError_t e = hipEventRecord(ev, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
+    if (e != hipSuccess) { smd_set_error("run_network: event: %s", hipGetErrorString(e)); return (int)e; }
+    side_pending_ = true;
+    for (int k = 0; k < K; ++k) {
+      const FilmResP& b = blk_[k];
+      { GemmEpilogue ep; ep.act = SMD_ACT_SWISH; ep.out_bf16 = W.f1[k]; ep.ld_outb = 4 * F; ep.pre_bf16 = W.zf1[k]; ep.ld_pre = 4 * F;
+        RC(dense_fwd(b.f1, W.emb, F, B, ep, side_)); }
+      { GemmEpilogue ep; ep.out_bf16 = W.p[k]; ep.ld_outb = 4 * F; RC(dense_fwd(b.f2, W.f1[k], 4 * F, B, ep, side_)); }
+      { GemmEpilogue ep; ep.out_f32 = W.ss[k]; ep.ld_out = 2 * M; RC(dense_fwd(b.ss, W.p[k], 4 * F, B, ep, side_)); }
+    }
+    e = hipEventRecord(film_ready, side_);
+    if (e != hipSuccess) { smd_set_error("run_network: event: %s", hipGetErrorString(e)); return (int)e; }
+  }
+
   float* y0 = W.y[0];
   if (d_.arch == 0) {
     {  // in_proj + positional encoding (models/ncsn.py:152-157)
@@ -496,7 +520,11 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
   // DenseResBlocks (models/shared.py:61-75) each with its own FiLM generator (models/ncsn.py:47-61,
   // 173-175 / 130-132).  Per-sample noise levels generate scale/shift here; the sampler reads the
   // per-timestep tables built by prepare_sampler() instead.
-  if (!t_ptr) RC(launch_noise_embed(W.s, B, F, W.emb, F, st));
+  if (!t_ptr && !film_ready) RC(launch_noise_embed(W.s, B, F, W.emb, F, st));
+  if (film_ready) {
+    hipError_t e = hipStreamWaitEvent(st, film_ready, 0);
+    if (e != hipSuccess) { smd_set_error("run_network: event: %s", hipGetErrorString(e)); return (int)e; }
+  }
   const bool f8 = fp8 && W.w8 && R % 256 == 0 && M % 256 == 0 && (M == 1024 || M == 2048);
   if (f8 && w8_dirty_) {           // e4m3 copies of the ResBlock weights (per output row), once per weight refresh
     for (int k = 0; k < K; ++k) {
@@ -516,6 +544,8 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
     const int ld_film = 2 * M;
     if (t_ptr) {
       scale = film_tables_ + (size_t)k * d_.num_timesteps * 2 * M;
+    } else if (film_ready) {
+      scale = W.ss[i];
     } else {
       { GemmEpilogue ep; ep.act = SMD_ACT_SWISH; ep.out_bf16 = W.f1[i]; ep.ld_outb = 4 * F;
         if (tr) { ep.pre_bf16 = W.zf1[i]; ep.ld_pre = 4 * F; }
@@ -653,11 +683,23 @@ int SmdEngine::backward_head(hipStream_t st) {
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 1;
       RC(ln_bwd(b, st));
     }
-    // FiLM generator (models/ncsn.py:52-61)
-    RC(launch_cast_pad_bf16(W.dss[k], B, 2 * M, W.dss_bf16[k], 2 * M, st));
-    RC(dense_bwd(p.ss, W.p[k], 4 * F, W.dss_bf16[k], 2 * M, B, W.dp[k], 4 * F, nullptr, 0, SMD_AUX_NONE, st, film_side != 0));
-    RC(dense_bwd(p.f2, W.f1[k], 4 * F, W.dp[k], 4 * F, B, W.df1[k], 4 * F, W.zf1[k], 4 * F, SMD_AUX_SWISH_GRAD, st, film_side != 0));
-    RC(dense_bwd(p.f1, W.emb, F, W.df1[k], 4 * F, B, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, film_side != 0));
+    // FiLM generator (models/ncsn.py:52-61).  Nothing on the main chain consumes its gradients (the noise embedding has
+    // no parameters behind it): with the side stream on, the whole chain -- cast, two dgrads, three wgrads -- leaves the
+    // main stream behind an event (dscale / dshift of this block are final after the LayerNorm backward above)
+    hipStream_t fs = st;
+    if (film_side_fwd && film_side && side_wgrad && side_ && tr_path) {     // (the tr_path = 0 fallback shares one scratch)
+      hipEvent_t ev = take_event();
+      SMD_ARG_CHECK(ev, "backward_head: cannot create an event");
+      hipError_t e = hipEventRecord(ev, st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
+      if (e != hipSuccess) { smd_set_error("backward_head: event: %s", hipGetErrorString(e)); return (int)e; }
+      fs = side_;
+      side_pending_ = true;
+    }
+    RC(launch_cast_pad_bf16(W.dss[k], B, 2 * M, W.dss_bf16[k], 2 * M, fs));
+    RC(dense_bwd(p.ss, W.p[k], 4 * F, W.dss_bf16[k], 2 * M, B, W.dp[k], 4 * F, nullptr, 0, SMD_AUX_NONE, fs, film_side != 0));
+    RC(dense_bwd(p.f2, W.f1[k], 4 * F, W.dp[k], 4 * F, B, W.df1[k], 4 * F, W.zf1[k], 4 * F, SMD_AUX_SWISH_GRAD, fs, film_side != 0));
+    RC(dense_bwd(p.f1, W.emb, F, W.df1[k], 4 * F, B, nullptr, 0, nullptr, 0, SMD_AUX_NONE, fs, film_side != 0));
   }
   if (d_.arch == 0) {
     // up (models/ncsn.py:171) and ln_f (:170)
@@ -726,7 +768,9 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       RC(ln_bwd(b, st));
     }
-    if (group_wgrad == 2) RC(flush_grouped_wgrads(st));    // this layer's four 128-wide wgrads as one side-stream launch
+    // this layer's four 128-wide wgrads as one side-stream launch; layer 0's wait for in_proj's (the 4-tile in_proj
+    // problem alone was a 17 us launch + a reduce of its own at the very end of the step)
+    if (group_wgrad == 2 && l > 0) RC(flush_grouped_wgrads(st));
   }
   return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dhb[0], E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
 }
