@@ -120,6 +120,8 @@ class SmdEngine {
   int loss_kind = 0;
   void set_used_alphas(const float* a) { used_alphas_ = a; }
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
+  int tail_on_main = 1;    // the last grouped wgrad launch of a step runs on the caller's stream (which would idle) while
+                           // the side stream drains its backlog
   int film_side_fwd = 1;   // training: FiLM generators (forward) and their backward chain run on the side stream
   int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
@@ -148,7 +150,7 @@ class SmdEngine {
   int join_side(hipStream_t st);
   int ln_bwd(LnBwdArgs& b, hipStream_t st);
   int flush_ln_reduce(hipStream_t st);
-  int flush_grouped_wgrads(hipStream_t st);
+  int flush_grouped_wgrads(hipStream_t st, bool on_caller_stream = false);
   std::vector<TnLaunch> deferred_wgrads_;
   TnLaunch pending256_;
   bool have_pending256_ = false;

@@ -103,11 +103,11 @@ int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY
 
 // The deferred 128-wide weight gradients (every operand is a saved activation or a per-use gradient slot, so
 // they can wait): grouped launches of <= 8 problems + one slab reduce each, on the side stream when enabled.
-int SmdEngine::flush_grouped_wgrads(hipStream_t st) {
+int SmdEngine::flush_grouped_wgrads(hipStream_t st, bool on_caller_stream) {
   if (deferred_wgrads_.empty()) return 0;
   hipStream_t ls = st;
   float* slab = W.tn_slab;
-  if (side_wgrad && side_) {
+  if (side_wgrad && side_ && !on_caller_stream) {
     hipEvent_t ev = take_event();
     SMD_ARG_CHECK(ev, "flush_grouped_wgrads: cannot create an event");
     hipError_t e = hipEventRecord(ev, st);
@@ -820,15 +820,16 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
       if (e != hipSuccess) { smd_set_error("loss_backward: %s", hipGetErrorString(e)); return (int)e; }
     }
     if (stage != 3) RC(backward_head(st));
-    if (stage == 1) {                              // output-stage gradients must be final before the DP all-reduce
-      RC(flush_ln_reduce(st));
-      RC(flush_grouped_wgrads(st));
-    }
+    if (stage == 1) RC(flush_ln_reduce(st));       // output-stage gradients must be final before the DP all-reduce
+    // the output stage's deferred wgrads (out_proj, up, FiLM generators) go to the side stream now: some of their operands
+    // were produced THERE (the FiLM backward chain), and the step's last grouped launch -- which runs on the caller's
+    // stream (tail_on_main) -- must only hold problems whose operands the caller's stream produced
+    if (stage != 3) RC(flush_grouped_wgrads(st));
   }
   if (stage == 0 || stage == 2) {
     RC(backward_stem(st));
     RC(flush_ln_reduce(st));                       // one launch for every pending LayerNorm dgamma/dbeta
-    RC(flush_grouped_wgrads(st));
+    RC(flush_grouped_wgrads(st, tail_on_main != 0));
   }
   return join_side(st);      // every gradient is complete on `st` when this returns (stage 1: the output stage)
 }
