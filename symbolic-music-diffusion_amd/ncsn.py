@@ -241,6 +241,13 @@ def denoising_score_matching_loss(batch, model: Model, sigmas, rng: PRNGKey, con
 ALD_COLLECTION_STEPS = 100                                                        # utils/ebm_utils.py:127
 
 
+def ald_collection_slot(collection_idx: np.ndarray, image_idx: int) -> int:
+    """utils/ebm_utils.py:149-156: ``idx = sum(arange(n) * in1d(collection_idx, image_idx)) + 1`` when any entry matches --
+    repeated linspace entries (len(sigmas) * T < 100) ADD UP, exactly like upstream -- else -1."""
+    hit = np.nonzero(np.asarray(collection_idx) == image_idx)[0]
+    return int(hit.sum()) + 1 if len(hit) else -1
+
+
 def _langevin_io(x, grad, alpha, noise_coef, rng, step, sample_offset, metrics, collect):
     io = _lib.LangevinIO()
     io.x, io.grad = x.data_ptr(), grad.data_ptr()
@@ -300,8 +307,7 @@ def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon
         for i in range(T):
             grad = model(x, sig_vec)                                                # :140
             image_idx = si * T + i + 1                                              # :149-156 (duplicates add up, as upstream)
-            hit = np.nonzero(cidx == image_idx)[0]
-            slot = int(hit.sum()) + 1 if len(hit) else -1
+            slot = ald_collection_slot(cidx, image_idx)
             k = si * T + i
             io = _langevin_io(x, grad, alpha, np.sqrt(np.float32(2) * alpha), rng, k, sample_offset, metrics[k],
                               collection[slot] if 0 < slot < n_coll else None)

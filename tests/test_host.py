@@ -312,3 +312,27 @@ def test_custom_ops_are_registered_and_have_no_cpu_path():
         xt, s = torch.ops.smd_amd.q_sample(torch.empty(4, 32, 42), torch.empty(1001), torch.empty(4, dtype=torch.int32),
                                            torch.empty(4, 32, 42))
         assert tuple(xt.shape) == (128, 42) and tuple(s.shape) == (4,)
+
+
+def test_langevin_host_logic_matches_the_oracle():
+    """Host-side pieces of the Langevin samplers: per-update key tables (utils/ebm_utils.py:133,233) and the collection
+    slot arithmetic (:149-156) incl. its behaviour when linspace repeats entries."""
+    import smd_amd.jax_random as J
+    import smd_amd.ncsn as N
+    key = O.jax_prngkey(5)
+    tk = J.ThreefryKey(int(key[0]), int(key[1]))
+    for consistent in (False, True):
+        step, infill = J.langevin_key_table(tk, 7, consistent=consistent)
+        sk, fk = O.jax_langevin_keys(key, 7, consistent=consistent)
+        assert [tuple(int(v) for v in r) for r in step] == [(int(k[0]), int(k[1])) for k in sk]
+        if not consistent:
+            assert [tuple(int(v) for v in r) for r in infill] == [(int(k[0]), int(k[1])) for k in fk]
+    for L, T in ((10, 100), (2, 50), (3, 4), (10, 5)):
+        cidx = np.linspace(1, L * T, 100).astype(np.int32)
+        for image_idx in range(1, L * T + 1):
+            assert N.ald_collection_slot(cidx, image_idx) == O.ald_collection_slot(cidx, image_idx)
+    cidx = np.linspace(1, 12, 100).astype(np.int32)                      # 12 updates: every value repeats 8-9 times
+    assert N.ald_collection_slot(cidx, 1) == sum(range(9)) + 1 and N.ald_collection_slot(cidx, 13) == -1
+    cidx = np.linspace(1, 1000, 100).astype(np.int32)
+    slots = [N.ald_collection_slot(cidx, i) for i in range(1, 1001)]
+    assert sorted(s for s in slots if s > 0) == list(range(1, 101))      # the usual case: each of the 100 slots once
