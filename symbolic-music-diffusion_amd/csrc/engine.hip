@@ -439,6 +439,10 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
   }
 
   float* y0 = W.y[0];
+  // bf16 trunk: inference (trunk_bf16 >= 1) and training (trunk_bf16 == 2); the same buffers, half of each
+  const bool tb = trunk_bf16_on();
+  auto ybk = [&](int k) { return reinterpret_cast<bf16_t*>(W.y[tr ? k : 0]); };
+  bf16_t* yb = ybk(0);
   if (d_.arch == 0) {
     {  // in_proj + positional encoding (models/ncsn.py:152-157)
       GemmEpilogue ep;
@@ -509,11 +513,13 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
         ln.x = W.h_last; ln.rows = R; ln.D = E; ln.gamma = P(ln_f_.g_off); ln.beta = P(ln_f_.b_off); ln.out = W.af;
         RC(launch_layernorm_fwd(ln, st));
       }
-      GemmEpilogue ep; ep.out_f32 = y0; ep.ld_out = M;
+      GemmEpilogue ep;
+      if (tb) { ep.out_bf16 = yb; ep.ld_outb = M; } else { ep.out_f32 = y0; ep.ld_out = M; }
       RC(dense_fwd(up_, W.af, E, R, ep, st));
     }
   } else {  // DenseDDPM stem, models/ncsn.py:129
-    GemmEpilogue ep; ep.out_f32 = y0; ep.ld_out = M;
+    GemmEpilogue ep;
+    if (tb) { ep.out_bf16 = yb; ep.ld_outb = M; } else { ep.out_f32 = y0; ep.ld_out = M; }
     RC(dense_fwd(in_proj_, W.x_bf16, Cp_, R, ep, st));
   }
 
@@ -561,7 +567,8 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       // e4m3 forward GEMMs: the LayerNorm writes the A operand as e4m3 + row scales (and, when training, the bf16 copy
       // the weight gradient contracts), the weights were quantised per output row above
       const size_t wo = (size_t)k * 2 * M * M, so = (size_t)k * 2 * M;
-      ln.x = y_in; ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off);
+      if (tb) { ln.x = nullptr; ln.x_bf16 = ybk(k); } else ln.x = y_in;
+      ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off);
       ln.out = tr ? W.ya1[i] : nullptr; ln.out_f8 = W.ya1_f8[i]; ln.out_scale = W.sa1[i];
       RC(launch_layernorm_fwd(ln, st));
       { GemmEpilogue ep; ep.bias = P(b.r1.b_off); ep.out_bf16 = W.o1[i]; ep.ld_outb = M;
@@ -569,21 +576,27 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off);
       ln.out = tr ? W.ya2[i] : nullptr; ln.out_f8 = W.ya2_f8[i]; ln.out_scale = W.sa2[i];
       RC(launch_layernorm_fwd(ln, st));
-      { GemmEpilogue ep; ep.bias = P(b.r2.b_off); ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M;
+      { GemmEpilogue ep; ep.bias = P(b.r2.b_off);
+        if (tb) { ep.res_bf16 = ybk(k); ep.ld_resb = M; ep.out_bf16 = ybk(k + 1); ep.ld_outb = M; }
+        else { ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M; }
         RC(launch_gemm_nt256_fp8(W.ya2_f8[i], M, W.sa2[i], W.w8 + wo + (size_t)M * M, M, W.w8s + so + M, R, M, M, ep, st)); }
       continue;
     }
-    ln.x = y_in; ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off); ln.out = W.ya1[i];
+    if (tb) { ln.x = nullptr; ln.x_bf16 = ybk(k); } else ln.x = y_in;
+    ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off); ln.out = W.ya1[i];
     RC(launch_layernorm_fwd(ln, st));
     { GemmEpilogue ep; ep.out_bf16 = W.o1[i]; ep.ld_outb = M; RC(dense_fwd(b.r1, W.ya1[i], M, R, ep, st)); }
     ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off); ln.out = W.ya2[i];
     RC(launch_layernorm_fwd(ln, st));
-    { GemmEpilogue ep; ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M;
+    { GemmEpilogue ep;
+      if (tb) { ep.res_bf16 = ybk(k); ep.ld_resb = M; ep.out_bf16 = ybk(k + 1); ep.ld_outb = M; }
+      else { ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M; }
       RC(dense_fwd(b.r2, W.ya2[i], M, R, ep, st)); }
   }
   {  // models/ncsn.py:177-178 / 133-134
     LnArgs ln;
-    ln.x = tr ? W.y[K] : W.y[0]; ln.rows = R; ln.D = M; ln.gamma = P(ln_o_.g_off); ln.beta = P(ln_o_.b_off);
+    if (tb) ln.x_bf16 = ybk(K); else ln.x = tr ? W.y[K] : W.y[0];
+    ln.rows = R; ln.D = M; ln.gamma = P(ln_o_.g_off); ln.beta = P(ln_o_.b_off);
     ln.out = W.ao;
     RC(launch_layernorm_fwd(ln, st));
     GemmEpilogue ep; ep.out_f32 = W.pred; ep.ld_out = C;
@@ -651,7 +664,8 @@ int SmdEngine::backward_head(hipStream_t st) {
   RC(dense_bwd(out_proj_, W.ao, M, W.dpred, Cp_, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
   {
     LnBwdArgs b;
-    b.f = ln_args(W.y[K], nullptr, R, ln_o_, params_);
+    const bool tbk = trunk_bf16_on();
+    b.f = tbk ? ln_args(nullptr, reinterpret_cast<bf16_t*>(W.y[K]), R, ln_o_, params_) : ln_args(W.y[K], nullptr, R, ln_o_, params_);
     b.dout = W.dA_M; b.dx = use_bf16_chain ? nullptr : W.dy; b.dx_bf16 = W.dyb[K];
     b.dgamma = G(ln_o_.g_off); b.dbeta = G(ln_o_.b_off);
     RC(ln_bwd(b, st));
@@ -673,7 +687,8 @@ int SmdEngine::backward_head(hipStream_t st) {
     RC(dense_bwd(p.r1, W.ya1[k], M, W.do1[k], M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
     {
       LnBwdArgs b;
-      b.f = ln_args(W.y[k], nullptr, R, p.ln1, params_);
+      b.f = trunk_bf16_on() ? ln_args(nullptr, reinterpret_cast<bf16_t*>(W.y[k]), R, p.ln1, params_)
+                            : ln_args(W.y[k], nullptr, R, p.ln1, params_);
       b.f.film_scale = W.ss[k]; b.f.film_shift = W.ss[k] + M; b.f.ld_film = 2 * M; b.f.rows_per_sample = S;
       b.f.swish = 1;
       b.dout = W.dA_M; b.dx_bf16 = W.dyb[k];

@@ -94,9 +94,10 @@ __device__ __forceinline__ void epilogue_quad(const float4 a, int row, int col, 
 // ---- 8-column form used by the 256x256 kernel: every lane owns 8 consecutive columns of a row; the global
 // operands of the epilogue (aux, fp32 residual) are fetched BEFORE the accumulators are staged so that a
 // whole pass of loads is in flight at once.  Supports: bias, pre_bf16, act, aux, res_f32 (+row mod), out_f32,
-// out_bf16 (alpha == 1, no res_bf16, no accumulate: see oct_ok()).
+// res_bf16, out_bf16 (alpha == 1, no accumulate: see oct_ok()).
 struct EpiPre8 {
   bf16x8_t aux;
+  bf16x8_t rb;
   float4 r0, r1;
 };
 __device__ __forceinline__ void epi8_prefetch(EpiPre8& p, int row, int col, const GemmEpilogue& ep) {
@@ -106,6 +107,7 @@ __device__ __forceinline__ void epi8_prefetch(EpiPre8& p, int row, int col, cons
     const float4* r = reinterpret_cast<const float4*>(ep.res_f32 + (size_t)rr * ep.ld_res + col);
     p.r0 = r[0]; p.r1 = r[1];
   }
+  if (ep.res_bf16) p.rb = *reinterpret_cast<const bf16x8_t*>(ep.res_bf16 + (size_t)row * ep.ld_resb + col);
 }
 __device__ __forceinline__ void epi8_apply(float (&v)[8], const float (&bias)[8], const EpiPre8& p, int row, int col,
                                            const GemmEpilogue& ep) {
@@ -137,6 +139,10 @@ __device__ __forceinline__ void epi8_apply(float (&v)[8], const float (&bias)[8]
     v[0] += p.r0.x; v[1] += p.r0.y; v[2] += p.r0.z; v[3] += p.r0.w;
     v[4] += p.r1.x; v[5] += p.r1.y; v[6] += p.r1.z; v[7] += p.r1.w;
   }
+  if (ep.res_bf16) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] += bf2f(p.rb[i]);
+  }
   if (ep.out_f32) {
     float4* o = reinterpret_cast<float4*>(ep.out_f32 + (size_t)row * ep.ld_out + col);
     o[0] = make_float4(v[0], v[1], v[2], v[3]);
@@ -161,7 +167,7 @@ inline int vec_ok(const GemmEpilogue& ep) {
 inline bool al8h(const void* p, int ld) { return p == nullptr || (((uintptr_t)p & 15) == 0 && ld % 8 == 0); }
 // the 8-column epilogue applies (N is a multiple of 256 there)
 inline bool oct_ok(const GemmEpilogue& ep) {
-  return ep.alpha == 1.0f && !ep.res_bf16 && !ep.accumulate && al4(ep.bias, 4) && al4(ep.res_f32, ep.ld_res) &&
+  return ep.alpha == 1.0f && !ep.accumulate && al4(ep.bias, 4) && al4(ep.res_f32, ep.ld_res) && al8h(ep.res_bf16, ep.ld_resb) &&
          al4(ep.out_f32, ep.ld_out) && al8h(ep.pre_bf16, ep.ld_pre) && al8h(ep.aux, ep.ld_aux) && al8h(ep.out_bf16, ep.ld_outb);
 }
 

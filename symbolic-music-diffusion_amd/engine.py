@@ -94,6 +94,9 @@ class Engine:
         # engines sharing one operand pack: a weight refresh through any handle invalidates every handle's e4m3 copies
         self._wstate = share_params_with._wstate if share_params_with is not None else {"ver": 0}
         self._wseen = -1
+        for kv in filter(None, os.environ.get("SMD_ENGINE_OPTS", "").split(",")):      # A/B runs: "key=value,key=value"
+            k, _, v = kv.partition("=")
+            _lib.check(self.L.smd_engine_set_option(h, k.strip().encode(), int(v)), f"SMD_ENGINE_OPTS {kv}")
         self._label_min = 1
         self._loss_kind = 0
         self.grads = self.m = self.v = self.ema = None
