@@ -64,7 +64,17 @@ int64_t smd_engine_wpack_elems(const smd_engine* e);        /* bf16 elements of 
 int64_t smd_engine_workspace_bytes(const smd_engine* e, int batch, int training);
 int64_t smd_engine_film_table_floats(const smd_engine* e);
 int smd_engine_padded_channels(const smd_engine* e);
-int smd_engine_set_option(smd_engine* e, const char* key, int value);  /* "tr_path": 1 | 0 */
+/* Per-handle options (set before the first bind unless noted; unknown keys return < 0).  Defaults are the shipped paths:
+ *   "tr_path" 1          weight gradients with transposing LDS reads (0: explicit-transpose fallback)
+ *   "side_wgrad" 0/1     weight-gradient GEMMs (and the gradient memset, FiLM chains) on the engine's low-priority side
+ *                        stream, joined inside smd_engine_loss_backward; the Python host turns it on for training handles
+ *   "group_wgrad" 2, "pair_wgrad" 1, "film_side" 1, "film_side_fwd" 1, "tail_on_main" 1   launch grouping of those GEMMs
+ *   "fused_encoder" 1, "fused_attn_bwd" 1, "mlp_hs" 1   fused encoder half-layers / hidden-split MLP (0: separate launches)
+ *   "resgrad_bf16" 1     DenseResBlock residual-gradient chain in bf16
+ *   "trunk_bf16" 2       2048-wide residual stream in bf16 (2: inference + training, 1: inference only, 0: fp32)
+ *   "fp8" 0/1            e4m3 DenseResBlock forward GEMMs (BASELINE config 5); "w8_dirty" 1: operand pack changed elsewhere
+ *   "label_min" 1/0      Philox labels in [1, T] (continuous_noise) or [0, T);  "loss_kind" 0/1  DDPM / score matching */
+int smd_engine_set_option(smd_engine* e, const char* key, int value);
 
 int smd_engine_bind_params(smd_engine* e, float* params, smd_bf16* wpack);
 int smd_engine_bind_train(smd_engine* e, float* grads, float* adam_m, float* adam_v, float* ema /*nullable*/,
