@@ -286,3 +286,56 @@ def test_jax_erfinv_matches_scipy():
     got = O.erfinv_f32(x).astype(np.float64)
     want = erfinv(x.astype(np.float64))
     assert np.max(np.abs(got - want) / (1 + np.abs(want))) < 2e-6
+
+
+def test_score_matching_and_langevin_closed_forms():
+    """Known answers for the NCSN-path restatements (utils/losses.py:129-179, utils/ebm_utils.py:89-271)."""
+    sig = O.create_noise_schedule(1.0, 0.01, 10, "geometric")
+    assert sig[0] == pytest.approx(1.0) and sig[-1] == pytest.approx(0.01) and sig[3] / sig[4] == pytest.approx(sig[0] / sig[1])
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 4, 6, generator=g, dtype=torch.float64)
+    eps = torch.randn(5, 4, 6, generator=g, dtype=torch.float64)
+    labels = np.array([0, 3, 9, 5, 1])
+    # a model that returns the exact target -eps / sigma has zero loss; the zero model has loss 0.5 sum eps^2 (sigma-free)
+    perfect = lambda xt, s: -(xt - x) / s ** 2
+    assert float(O.denoising_score_matching_loss(x, perfect, sig, labels, eps, False, "sum")) < 1e-20
+    zero = lambda xt, s: torch.zeros_like(xt)
+    got = O.denoising_score_matching_loss(x, zero, sig, labels, eps, False, "none")
+    assert torch.allclose(got, 0.5 * (eps ** 2).sum(dim=(1, 2)), rtol=1e-10)
+    # continuous noise on a decreasing schedule: uniform(minval = sigmas[l-1], maxval = sigmas[l]) is its minval
+    lab1 = np.array([1, 4, 9, 2, 7])
+    assert np.array_equal(O.dsm_used_sigmas(sig, lab1, True), sig[lab1 - 1])
+    assert np.array_equal(O.dsm_used_sigmas(sig, lab1, True, np.full(5, 0.7, np.float32)), sig[lab1 - 1])
+    inc = sig[::-1].copy()
+    with pytest.raises(ValueError):
+        O.dsm_used_sigmas(inc, lab1, True)
+    mid = O.dsm_used_sigmas(inc, lab1, True, np.full(5, 0.5, np.float32))
+    assert np.allclose(mid, 0.5 * (inc[lab1 - 1] + inc[lab1]), rtol=1e-6)
+
+    # annealed Langevin with a zero score and zero noise leaves the state alone; alpha = eps (sigma / sigma_L)^2
+    init = torch.randn(3, 4, 6, generator=g, dtype=torch.float64)
+    zeros = lambda *a: torch.zeros(3, 4, 6, dtype=torch.float64)
+    s3 = np.array([1.0, 0.1, 0.05], np.float32)
+    st, coll, met = O.annealed_langevin_dynamics(zero, s3, init, 2e-5, 4, True, zeros)
+    assert torch.equal(st, init) and coll.shape == (102, 3, 4, 6) and met.shape == (4, 3, 4)
+    assert torch.allclose(met[2, :, 0], torch.tensor([2e-5 * 400, 2e-5 * 4, 2e-5], dtype=torch.float64), rtol=1e-5)
+    assert torch.allclose(met[0], torch.full((3, 4), 1e-5, dtype=torch.float64))          # sqrt(0 + 1e-10)
+    # a score pointing at the origin shrinks the state by (1 - alpha) per update; the denoise step by (1 - sigma_L^2)
+    pull = lambda xt, s: -xt
+    st, _, _ = O.annealed_langevin_dynamics(pull, s3, init, 2e-5, 2, True, zeros)
+    a = [2e-5 * (float(s) / 0.05) ** 2 for s in s3]
+    want = init * np.prod([(1 - float(np.float32(ai))) ** 2 for ai in a]) * (1 - 0.05 ** 2)
+    assert torch.allclose(st, want, rtol=1e-5)
+    # infill: the masked part is the template + sigma * noise of the last update, whatever the score does
+    mask = torch.zeros(3, 4, 6, dtype=torch.float64)
+    mask[:, :2] = 1
+    tmpl = torch.ones(3, 4, 6, dtype=torch.float64)
+    noise = torch.randn(3, 4, 6, generator=g, dtype=torch.float64)
+    st, coll, _ = O.annealed_langevin_dynamics(pull, s3, init, 2e-5, 2, False, zeros, True, tmpl, mask, lambda si, i: noise)
+    assert torch.allclose(st[:, :2], (tmpl + 0.05 * noise)[:, :2], rtol=1e-6) and torch.equal(coll[0][:, :2], tmpl[:, :2])
+    # consistent sampler: beta = sqrt(1 - (1 - eps / sigma_L^2)^2); the last update adds no noise (next sigma = 0)
+    ones = lambda i: torch.ones(3, 4, 6, dtype=torch.float64)
+    st, met = O.consistent_langevin_dynamics(zero, s3, init, 5e-4, False, ones)
+    beta = (1 - (1 - 5e-4 / 0.05 ** 2) ** 2) ** 0.5
+    assert torch.allclose(st, init + beta * (0.1 + 0.05), rtol=1e-5) and met.shape == (4, 3, 1)
+    assert float(met[3, 2, 0]) == pytest.approx(1e-5)                                     # noise norm of the last level: 0
