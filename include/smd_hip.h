@@ -256,7 +256,8 @@ int smd_layernorm_bwd(const float* x, int rows, int D, const float* gamma, const
                       int swish, const smd_bf16* dout, float* dx, float* dgamma, float* dbeta, float* dscale,
                       float* dshift, float* partial, int64_t partial_elems, void* stream);
 /* flax.nn.SelfAttention core, models/ncsn.py:161 */
-/* the engine's form of the LayerNorm backward: optional fp32 residual gradient `dres` added to dx (may alias dx: the
+/* (every LayerNorm backward WRITES dgamma / dbeta -- the sum over its row groups -- it does not accumulate into them)
+ * the engine's form of the LayerNorm backward: optional fp32 residual gradient `dres` added to dx (may alias dx: the
  * in-place residual-gradient stream), optional bf16 copy of dx, bf16 or fp32 input */
 int smd_layernorm_bwd_ex(const float* x, const smd_bf16* x_bf16, int rows, int D, const float* gamma, const float* beta,
                          const smd_bf16* dout, const float* dres, float* dx, smd_bf16* dx_bf16, float* dgamma, float* dbeta,

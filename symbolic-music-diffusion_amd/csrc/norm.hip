@@ -701,7 +701,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     const int which = c / D, cc = c - which * D;
     float* dst = which ? dbeta : dgamma;
     const int l = threadIdx.x;
-    dst[cc] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    dst[cc] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);      // written, not accumulated: no gradient memset
   }
 }
 
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_batched_kernel(LnReduceTabl
     const int which = c / D, cc = c - which * D;
     float* dst = which ? en.dbeta : en.dgamma;
     const int l = threadIdx.x;
-    dst[cc] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    dst[cc] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);      // written, not accumulated: no gradient memset
   }
 }
 

@@ -258,3 +258,37 @@ def test_data_parallel_engine_equivalence_single_gpu():
     # Measured: 4.8e-5 whole vector, 1.8e-3 worst tensor.
     assert whole < 2e-4
     assert worst < 1e-2
+
+
+@pytest.mark.parametrize("arch,C,B", [("TransformerDDPM", 512, 256), ("TransformerDDPM", 42, 8), ("DenseDDPM", 512, 64),
+                                      ("DenseDDPM", 42, 64)])
+def test_every_gradient_element_is_written_without_the_memset(arch, C, B):
+    """The default path no longer zeroes the 102 MB gradient buffer before a step (engine option grad_memset = 2): every
+    element must be overwritten.  Poison the buffer with NaN, run a step -- also in the two data-parallel stages -- and
+    require the result to be finite and bitwise equal to the same step with the memset forced."""
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    cfg = NetConfig(architecture=arch, data_channels=C, seq_len=32, num_timesteps=1000)
+    model = N.Model(cfg, "cuda:0", seed=3)
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    g = torch.Generator().manual_seed(9)
+    shape = (B, C) if arch == "DenseDDPM" else (B, 32, C)
+    x0 = torch.clamp(0.25 * torch.randn(*shape, generator=g), -1, 1).cuda()
+    labels = torch.randint(1, 1001, (B,), generator=g).int().cuda()
+    eps = torch.randn(*shape, generator=g).cuda()
+    eng.set_option("grad_memset", 1)
+    eng.loss_backward(x0, labels, eps, stage=0)
+    torch.cuda.synchronize()
+    ref = eng.grads.clone()
+    assert torch.isfinite(ref).all()
+    eng.set_option("grad_memset", 2)
+    for stages in ((0,), (1, 2)):
+        eng.grads.fill_(float("nan"))
+        for st_ in stages:
+            eng.loss_backward(x0 if st_ != 2 else None, labels if st_ != 2 else None, eps if st_ != 2 else None, stage=st_)
+        torch.cuda.synchronize()
+        bad = int((~torch.isfinite(eng.grads)).sum())
+        assert bad == 0, f"{bad} gradient elements were not written (stages {stages})"
+        assert torch.equal(eng.grads, ref)
