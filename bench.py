@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--dp-buckets", type=int, default=1, help="N > 1 GPUs: chunks per gradient all-reduce stage (GradComm)")
     ap.add_argument("--dp-payload", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1 GPUs: wire format of the gradient all-reduce (bf16 halves the xGMI bytes; off by default)")
+    ap.add_argument("--sampler-chains", type=int, default=2, choices=[1, 2],
+                    help="graph-replayed sampling as two concurrent half-batch chains (default) or one chain")
     ap.add_argument("--no-roofline-microbench", action="store_true",
                     help="skip the back-to-back launches of the dominant kernel (profiling runs: the trace then holds the timed loops only)")
     return ap.parse_args()
@@ -161,42 +163,61 @@ def main():
         train_step(N.diffusion_loss, x0, opt, betas, key, 1e-3, grad_clip=1.0, comm=comm, lr_gamma=0.98,
                    lr_interval=10000, sample_offset=rank * B, global_batch=B * world)
 
-    # ---- sampler state (replicas: each rank walks its own B sequences)
-    eng = model.engine
-    eng.set_schedule(betas, with_sampler=True)
-    eng.bind(B, training=False)
-    eng.prepare_sampler()
+    # ---- sampler state (replicas: each rank walks its own B sequences).  With graph replay the batch is walked as two
+    # concurrent half-batch chains on two streams, exactly as ncsn.diffusion_dynamics does (--sampler-chains 1: one chain).
+    nchains = 2 if (a.sampler_chains == 2 and not a.no_graph and B % 2 == 0 and (B // 2) * 32 % 256 == 0) else 1
+    engines = model.chain_engines(2) if nchains == 2 else [model.engine]
+    hB = B // nchains
     x = torch.empty(B, 32, 512, device=dev)
-    eng.init_state(x, 4321, rank * B)
-    t_ptr = torch.tensor([999], dtype=torch.int32, device=dev)
-    metrics_partial = torch.zeros(1000, B, 3, device=dev)
-    collection = torch.zeros(41, B, 32, 512, device=dev)
-    io = lib.SampleIO()
-    io.x, io.t_ptr = x.data_ptr(), t_ptr.data_ptr()
-    io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B
-    io.metrics_partial, io.collection, io.slot_table = metrics_partial.data_ptr(), collection.data_ptr(), eng.slot_table.data_ptr()
-    graph = None
+    chains = []
+    nk_d = None
     if a.rng_impl == "threefry":          # the reference's per-iteration noise keys; normals drawn inside the fused step
         import smd_amd.jax_random as J
         _ik, nk = J.sampler_key_tables(N.make_key(7, "threefry"), 1000)
         nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
-        io.tf_noise_keys, io.tf_n_total, io.tf_t0 = nk_d.data_ptr(), world * B * 32 * 512, 999
+    for c, eng in enumerate(engines):
+        eng.set_schedule(betas, with_sampler=True)
+        eng.bind(hB, training=False)
+        eng.prepare_sampler()
+        xc = x[c * hB:(c + 1) * hB]
+        eng.init_state(xc, 4321, rank * B + c * hB)
+        ch = dict(eng=eng, x=xc, t_ptr=torch.tensor([999], dtype=torch.int32, device=dev),
+                  metrics=torch.zeros(1000, hB, 3, device=dev), coll=torch.zeros(41, hB, 32, 512, device=dev),
+                  graph=None, stream=torch.cuda.Stream(device=dev) if nchains > 1 else None)
+        io = lib.SampleIO()
+        io.x, io.t_ptr = xc.data_ptr(), ch["t_ptr"].data_ptr()
+        io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B + c * hB
+        io.metrics_partial, io.collection, io.slot_table = ch["metrics"].data_ptr(), ch["coll"].data_ptr(), eng.slot_table.data_ptr()
+        if nk_d is not None:
+            io.tf_noise_keys, io.tf_n_total, io.tf_t0 = nk_d.data_ptr(), world * B * 32 * 512, 999
+        ch["io"] = io
+        chains.append(ch)
 
-    def sample_step():
-        eng.sample_step(io)
+    def run_chain(ch):
+        if ch["graph"] is not None:
+            ch["graph"].replay()
+        else:
+            ch["eng"].sample_step(ch["io"])
 
     walked = [0]
 
     def one_sample():
         # a reverse walk has T = 1000 iterations: start over before t would pass 0 (the kernels also refuse t < 0)
         if walked[0] >= 990:
-            t_ptr.fill_(999)
+            for ch in chains:
+                if ch["stream"] is not None:
+                    with torch.cuda.stream(ch["stream"]):
+                        ch["t_ptr"].fill_(999)
+                else:
+                    ch["t_ptr"].fill_(999)
             walked[0] = 0
         walked[0] += 1
-        if graph is not None:
-            graph.replay()
-        else:
-            sample_step()
+        for ch in chains:
+            if ch["stream"] is not None:
+                with torch.cuda.stream(ch["stream"]):
+                    run_chain(ch)
+            else:
+                run_chain(ch)
 
     do_train, do_sample = a.mode in ("both", "train"), a.mode in ("both", "sample")
     log(f"rank {rank}: model + buffers ready, warming up")
@@ -207,17 +228,22 @@ def main():
             one_sample()
     if do_sample and not a.no_graph:
         # weights change under training: tables/operand pack are refreshed per sampling run in the real
-        # sampler; here the step content is what is timed, so one captured step is replayed.
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            sample_step()
-        torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            sample_step()
+        # sampler; here the step content is what is timed, so one captured step per chain is replayed.
+        torch.cuda.synchronize()
+        for ch in chains:
+            s = ch["stream"] if ch["stream"] is not None else torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                ch["eng"].sample_step(ch["io"])
+            s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                ch["eng"].sample_step(ch["io"])
+            ch["graph"] = g
         one_sample()
-    t_ptr.fill_(999)
+    torch.cuda.synchronize()
+    for ch in chains:
+        ch["t_ptr"].fill_(999)
     walked[0] = 0
 
     def barrier():
@@ -366,7 +392,8 @@ def main():
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,
-                       "sample_step": "eager" if a.no_graph else "hipGraph replay", "rng": a.rng_impl},
+                       "sample_step": "eager" if a.no_graph else ("hipGraph replay, 2 concurrent half-batch chains" if nchains == 2 else "hipGraph replay"),
+                       "rng": a.rng_impl},
             "train_steps_per_sec": round(world * a.steps / t_train, 3) if do_train else None,
             "sample_steps_per_sec": round(world * a.steps / t_sample, 3) if do_sample else None,
             "seq_steps_per_sec": round(world * n_eval * B / total, 1),

@@ -88,6 +88,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   if (std::string(key) == "trunk_bf16") { e->impl.trunk_bf16 = value; return 0; }
+  if (std::string(key) == "nt256_min_tiles") { e->impl.nt256_min_tiles = value; return 0; }
   if (std::string(key) == "grad_memset") { e->impl.grad_memset = value; return 0; }
   if (std::string(key) == "tail_on_main") { e->impl.tail_on_main = value ? 1 : 0; return 0; }
   if (std::string(key) == "film_side_fwd") { e->impl.film_side_fwd = value ? 1 : 0; return 0; }

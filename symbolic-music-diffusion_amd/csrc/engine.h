@@ -126,6 +126,7 @@ class SmdEngine {
   // oracle, gradient parity unchanged (5.7e-3); sample step +9.6 %, train step +2.2 %.
   int trunk_bf16 = 2;      // 0: fp32 trunk everywhere; 1: bf16 in inference workspaces only; 2: training too (default)
   bool trunk_bf16_on() const { return d_.mlp_dims % 8 == 0 && (training_ ? trunk_bf16 == 2 : trunk_bf16 >= 1); }
+  int nt256_min_tiles = 0; // > 0: Dense layers take the 256x256 GEMM from this many tiles up (concurrent sampling chains: 128)
   int grad_memset = 2;     // 0 never, 1 always, 2 (default): only with the tr_path = 0 fallback wgrads
   int tail_on_main = 1;    // the last grouped wgrad launch of a step runs on the caller's stream (which would idle) while
                            // the side stream drains its backlog

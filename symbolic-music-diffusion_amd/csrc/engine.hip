@@ -389,6 +389,8 @@ int SmdEngine::refresh_weights(hipStream_t st) {
 // ------------------------------------------------------------------ dense helpers
 int SmdEngine::dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmEpilogue ep, hipStream_t st) {
   ep.bias = P(p.b_off);
+  if (nt256_min_tiles > 0 && gemm_nt256_eligible(M, p.N, p.Kp, ep, nt256_min_tiles))
+    return launch_gemm_nt256(A, lda, wpack_ + p.Wt_off, p.Kp, M, p.N, p.Kp, ep, st);
   return launch_gemm_nt(A, lda, wpack_ + p.Wt_off, p.Kp, M, p.N, p.Kp, ep, st);
 }
 

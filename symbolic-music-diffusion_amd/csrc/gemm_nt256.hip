@@ -363,13 +363,15 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict_
 
 }  // namespace
 
-bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep) {
+bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep, int min_tiles) {
   if (!smd_epi::oct_ok(ep)) return false;
   const int mode = smd_tuning_get("gemm_nt256");
   if (mode == 0 || M % TM || N % TN || K % (2 * TK) || K < 2 * TK) return false;
   if (mode == 2) return true;                  // forced (tests)
   const long tiles = (long)(M / TM) * (N / TN);
-  return tiles >= 192;     // at least ~3/4 of the 256 CUs busy; smaller grids are better served by 128-wide tiles
+  // at least ~3/4 of the 256 CUs busy (192): smaller grids are better served by 128-wide tiles -- unless the caller runs
+  // two such streams side by side (concurrent sampling chains ask for 128)
+  return tiles >= min_tiles;
 }
 
 int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,

@@ -37,7 +37,7 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
                    const GemmEpilogue& ep, hipStream_t st);
 
 // 256x256x64 8-phase kernel (gemm_nt256.hip); launch_gemm_nt dispatches to it when eligible and enabled
-bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep);
+bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep, int min_tiles = 192);
 int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N, int K,
                       const GemmEpilogue& ep, hipStream_t st);
 // the same tile and pipeline on OCP e4m3 operands with one E8M0 (power-of-two) scale per row of A and of Bt (dword

@@ -96,6 +96,17 @@ class Model:
         dev = self.engine.device
         return torch.ops.smd_amd.eps_forward(x.to(dev, torch.float32), cond.to(dev, torch.float32), self._op_id)
 
+    def chain_engines(self, n: int) -> List[Engine]:
+        """``n`` inference handles on this model's parameters and operand pack for concurrent sampling chains; their large
+        GEMMs take the 256x256 kernel from 128 tiles up (half the CUs each: two chains fill the chip)."""
+        if getattr(self, "_chain_engines", None) is None or len(self._chain_engines) != n:
+            self._chain_engines = []
+            for _ in range(n):
+                e = Engine(self.cfg, str(self.engine.device), share_params_with=self.engine)
+                e.set_option("nt256_min_tiles", 128)
+                self._chain_engines.append(e)
+        return self._chain_engines
+
     def train_engine(self, ema: bool) -> Engine:
         if self._train_engine is None:
             self._train_engine = Engine(self.cfg, str(self.engine.device), share_params_with=self.engine)
@@ -408,6 +419,16 @@ def collate_sampling_metrics(ld_metrics):
     return out
 
 
+def _sampler_chains(model: "Model", B: int, graphed: bool) -> int:
+    """2 when the graph-replayed walk of B sequences is split into two concurrent chains (SMD_SAMPLER_CHAINS=1 turns it off)."""
+    import os
+    if not graphed or os.environ.get("SMD_SAMPLER_CHAINS", "2") != "2":
+        return 1
+    eng = model.engine
+    rows = (B // 2) * eng.S
+    return 2 if (B % 2 == 0 and B >= 128 and rows % 256 == 0 and eng.cfg.mlp_dims % 256 == 0) else 1
+
+
 def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=None, denoise=None, infill=False,
                        infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
                        infill_noises: Optional[Callable] = None, t_start: Optional[int] = None, t_stop: int = 0,
@@ -430,11 +451,6 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     if tuple(init.shape[1:]) != eng.cfg.sample_shape:
         raise ValueError(f"init shape {tuple(init.shape)} != (B, {eng.cfg.sample_shape})")
     nT = len(betas)
-    _ensure_schedule(eng, betas, with_sampler=True)
-    eng.bind(B, training=False)
-    eng.refresh_weights()          # the fp32 master may have been trained since the last call
-    eng.prepare_sampler()          # FiLM scale/shift tables for all T noise levels (3 small GEMMs per block)
-
     if infill:
         inf_s = torch.as_tensor(infill_samples).to(dev, torch.float32).contiguous()
         inf_m = torch.as_tensor(infill_masks).to(dev, torch.float32).contiguous()
@@ -443,82 +459,100 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
         inf_s = inf_m = None
         start = init
     x = init.clone()
-    collection = torch.zeros((COLLECTION_STEPS + 1, *init.shape), dtype=torch.float32, device=dev)   # :322
-    collection[0] = start                                                          # :323
-    metrics_partial = torch.zeros((nT, B, 3), dtype=torch.float32, device=dev)
     t_hi = nT - 1 if t_start is None else int(t_start)
-    t_ptr = torch.tensor([t_hi], dtype=torch.int32, device=dev)
-    eng.load_state(x)
-
-    io = _lib.SampleIO()
-    io.x = x.data_ptr(); io.t_ptr = t_ptr.data_ptr()
-    io.seed_lo = rng.seed & 0xFFFFFFFF; io.seed_hi = (rng.seed >> 32) & 0xFFFFFFFF
-    io.sample_offset = sample_offset
-    io.infill_samples = None if inf_s is None else inf_s.data_ptr()
-    io.infill_masks = None if inf_m is None else inf_m.data_ptr()
-    io.metrics_partial = metrics_partial.data_ptr()
-    io.collection = collection.data_ptr()
-    io.slot_table = eng.slot_table.data_ptr()
     steps = list(range(t_hi, t_stop - 1, -1))
     explicit = noises is not None or infill_noises is not None
     jax_mode = isinstance(rng, ThreefryKey) and not explicit
+    graphed = use_graph and not explicit and len(steps) > 1
+    per = int(np.prod(init.shape[1:]))
+    n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
+    nk_d = ik_d = None
     if jax_mode:
         # the reference's own draws: the three splits per iteration (:329,342,360) are unrolled on the host into key
         # tables; the fused reverse step reads row (t_hi - t) on the device and evaluates jax.random.normal for its
         # elements of the global (N, S, C) array in place of its Philox draw
-        per = int(np.prod(init.shape[1:]))
-        n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
         ik, nk = _jr.sampler_key_tables(rng, len(steps))
         nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
         ik_d = torch.from_numpy(ik.view(np.int32).copy()).to(dev) if infill else None
-        io.tf_noise_keys = nk_d.data_ptr()
-        io.tf_infill_keys = None if ik_d is None else ik_d.data_ptr()
-        io.tf_n_total = n_glob
-        io.tf_t0 = t_hi
-        if use_graph and len(steps) > 1:
-            s = torch.cuda.Stream(device=dev)
-            s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):
-                eng.sample_step(io)                      # warm-up (also t = t_hi)
-            torch.cuda.current_stream(dev).wait_stream(s)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                eng.sample_step(io)
-            for _ in steps[1:]:
-                graph.replay()
-        else:
-            for _ in steps:
-                eng.sample_step(io)
-    elif explicit:
+
+    # Two concurrent half-batch chains (graph replay only): samples are independent, so the batch is walked as two chains
+    # of B/2 on two streams, each a replayed graph of its own engine handle; one chain's launch-latency-bound encoder
+    # kernels and GEMM epilogues then overlap the other's MFMA phases (-5 % per step at B = 256, profiles/README.md).
+    # Draws are keyed by the GLOBAL sample index, so the result does not depend on the split.
+    nchains = _sampler_chains(model, B, graphed)
+    engines = model.chain_engines(nchains) if nchains > 1 else [eng]
+    h = B // nchains
+    chains = []
+    for c, e in enumerate(engines):
+        _ensure_schedule(e, betas, with_sampler=True)
+        e.bind(h, training=False)
+        if c == 0:
+            e.refresh_weights()    # the fp32 master may have been trained since the last call (the operand pack is shared)
+        e.prepare_sampler()        # FiLM scale/shift tables for all T noise levels (3 small GEMMs per block)
+        lo, hi = c * h, (c + 1) * h
+        ch = dict(eng=e, x=x[lo:hi], coll=torch.zeros((COLLECTION_STEPS + 1, h, *init.shape[1:]), dtype=torch.float32, device=dev),
+                  metrics=torch.zeros((nT, h, 3), dtype=torch.float32, device=dev),
+                  t_ptr=torch.tensor([t_hi], dtype=torch.int32, device=dev))
+        ch["coll"][0] = start[lo:hi]                                              # :322-323
+        e.load_state(ch["x"])
+        io = _lib.SampleIO()
+        io.x = ch["x"].data_ptr(); io.t_ptr = ch["t_ptr"].data_ptr()
+        io.seed_lo = rng.seed & 0xFFFFFFFF; io.seed_hi = (rng.seed >> 32) & 0xFFFFFFFF
+        io.sample_offset = sample_offset + lo
+        io.infill_samples = None if inf_s is None else inf_s[lo:hi].data_ptr()
+        io.infill_masks = None if inf_m is None else inf_m[lo:hi].data_ptr()
+        io.metrics_partial = ch["metrics"].data_ptr()
+        io.collection = ch["coll"].data_ptr()
+        io.slot_table = e.slot_table.data_ptr()
+        if jax_mode:
+            io.tf_noise_keys = nk_d.data_ptr()
+            io.tf_infill_keys = None if ik_d is None else ik_d.data_ptr()
+            io.tf_n_total = n_glob
+            io.tf_t0 = t_hi
+        ch["io"] = io
+        chains.append(ch)
+
+    if explicit:
+        ch = chains[0]
         zbuf = torch.zeros_like(x)
         izbuf = torch.zeros_like(x) if infill else None
-        io.z_in = zbuf.data_ptr()
-        io.infill_z_in = None if izbuf is None else izbuf.data_ptr()
+        ch["io"].z_in = zbuf.data_ptr()
+        ch["io"].infill_z_in = None if izbuf is None else izbuf.data_ptr()
         for t in steps:
             if t > 0 and noises is not None:
                 zbuf.copy_(torch.as_tensor(noises(t)).to(dev, torch.float32))
             if t > 0 and izbuf is not None and infill_noises is not None:
                 izbuf.copy_(torch.as_tensor(infill_noises(t)).to(dev, torch.float32))
-            eng.sample_step(io)
-    elif use_graph and len(steps) > 1:
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            eng.sample_step(io)                      # warm-up (also t = t_hi)
-        torch.cuda.current_stream(dev).wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            eng.sample_step(io)
+            ch["eng"].sample_step(ch["io"])
+    elif graphed:
+        cur = torch.cuda.current_stream(dev)
+        for ch in chains:
+            st = torch.cuda.Stream(device=dev)
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ch["eng"].sample_step(ch["io"])              # warm-up (also t = t_hi)
+            ch["stream"] = st
+        for ch in chains:
+            ch["stream"].synchronize()
+            ch["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ch["graph"], stream=ch["stream"]):
+                ch["eng"].sample_step(ch["io"])
         for _ in steps[1:]:
-            graph.replay()
+            for ch in chains:
+                with torch.cuda.stream(ch["stream"]):
+                    ch["graph"].replay()
+        for ch in chains:
+            cur.wait_stream(ch["stream"])
     else:
         for _ in steps:
-            eng.sample_step(io)
+            chains[0]["eng"].sample_step(chains[0]["io"])
 
+    collection = chains[0]["coll"] if nchains == 1 else torch.cat([ch["coll"] for ch in chains], dim=1)
+    metrics_partial = chains[0]["metrics"] if nchains == 1 else torch.cat([ch["metrics"] for ch in chains], dim=1)
     # ld_metrics rows (grad_norm, step_norm, alpha_prod, noise_norm), one column per iteration (:380-405)
     denom = float(B) if eng.S == 1 else float(B * eng.C)
     per_t = metrics_partial.sum(dim=1) / denom                                      # (T, 3) indexed by t
-    ap = eng._sched_tensors["coef"][:, 5]
+    ap = chains[0]["eng"]._sched_tensors["coef"][:, 5]
     ld = torch.zeros((4, nT, 1), dtype=torch.float32, device=dev)
     idx = torch.tensor(steps, device=dev, dtype=torch.long)
     rows = torch.tensor([nT - 1 - t for t in steps], device=dev, dtype=torch.long)
