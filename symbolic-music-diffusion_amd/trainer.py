@@ -200,18 +200,13 @@ class GradComm:
                 self._reduce(c)
 
     def wait(self) -> None:
+        import contextlib
         cuda = self._stream is not None
-        ctx = torch.cuda.stream(self._stream) if cuda else None
-        if ctx is not None:
-            ctx.__enter__()
-        try:
+        with (torch.cuda.stream(self._stream) if cuda else contextlib.nullcontext()):
             for w in self._works:
                 w.wait()                    # on GPUs: orders the comm stream after the collective, no host block
             for chunk, buf in self._pending:
                 chunk.copy_(buf)            # widen bf16 -> fp32 in place
-        finally:
-            if ctx is not None:
-                ctx.__exit__(None, None, None)
         self._works.clear()
         self._pending.clear()
         if cuda:
