@@ -73,7 +73,10 @@ int smd_engine_padded_channels(const smd_engine* e);
  *   "resgrad_bf16" 1     DenseResBlock residual-gradient chain in bf16
  *   "trunk_bf16" 2       2048-wide residual stream in bf16 (2: inference + training, 1: inference only, 0: fp32)
  *   "fp8" 0/1            e4m3 DenseResBlock forward GEMMs (BASELINE config 5); "w8_dirty" 1: operand pack changed elsewhere
- *   "label_min" 1/0      Philox labels in [1, T] (continuous_noise) or [0, T);  "loss_kind" 0/1  DDPM / score matching */
+ *   "label_min" 1/0      Philox labels in [1, T] (continuous_noise) or [0, T);  "loss_kind" 0/1  DDPM / score matching
+ *   "grad_memset" 2      0 never / 1 always / 2 only with the tr_path = 0 fallback: zero the gradient buffer before a step
+ *                        (every gradient element is written, not accumulated, by the default kernels)
+ *   "nt256_min_tiles" 0  > 0: Dense layers take the 256x256 GEMM from this many output tiles up (default rule: 192) */
 int smd_engine_set_option(smd_engine* e, const char* key, int value);
 
 int smd_engine_bind_params(smd_engine* e, float* params, smd_bf16* wpack);
