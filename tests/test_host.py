@@ -336,3 +336,20 @@ def test_langevin_host_logic_matches_the_oracle():
     cidx = np.linspace(1, 1000, 100).astype(np.int32)
     slots = [N.ald_collection_slot(cidx, i) for i in range(1, 1001)]
     assert sorted(s for s in slots if s > 0) == list(range(1, 101))      # the usual case: each of the 100 slots once
+
+
+def test_cli_objective_and_sampler_gates():
+    """--loss / --sampling values the engine covers (utils/losses.py: dsm, ddpm; utils/ebm_utils.py: ald, cas, ddpm) are
+    accepted by the drivers' gate, everything else exits before any GPU work."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    tr = importlib.import_module("train_ncsn")
+    sm = importlib.import_module("sample_ncsn")
+    with pytest.raises(SystemExit, match="ssm needs a double backward"):
+        tr.main(["train_ncsn.py", "--loss=ssm", "--sampling=ddpm", "--synthetic"])
+    from smd_amd.flags import FlagError
+    with pytest.raises(FlagError, match="ald.cas.ddpm"):                  # the enum itself rejects anything else (:57-58)
+        sm.main(["sample_ncsn.py", "--sampling=hmc", "--synthetic"])
+    with pytest.raises(SystemExit, match="DDPM mode"):
+        sm.main(["sample_ncsn.py", "--sampling=ald", "--interpolate", "--synthetic"])
