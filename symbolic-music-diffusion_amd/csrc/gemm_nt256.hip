@@ -81,8 +81,10 @@ __device__ __forceinline__ void read_b(bf16x8_t (&b)[4], const lds_byte_ptr (&ad
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) b[ks] = *reinterpret_cast<lds_frag_ptr>(ad[ks] + off);
 }
-// e4m3: ad[ks] (ks = 0, 1) = address of the lane's 32 contiguous bytes of 64-wide step ks.  Read as two bf16x8-typed
-// 16-byte loads like the bf16 kernel's (with an int-typed 32-byte load hipcc orders every ds_read behind ALL outstanding
+// e4m3: ad[ks] / ad[ks + 2] (ks = 0, 1) = addresses of the two 16-byte chunks (logical chunk L and L + 1) of the lane's 32
+// bytes of 64-wide step ks -- swizzled independently over all eight chunk positions of the row like the bf16 kernel's
+// (a pair-preserving 4-position swizzle made every ds_read_b128 a 2-way bank conflict: 46 % of the LDS cycles, PMC).
+// Read as two bf16x8-typed 16-byte loads like the bf16 kernel's (with an int-typed 32-byte load hipcc orders every ds_read behind ALL outstanding
 // LDS-DMA -- s_waitcnt vmcnt(0) in every phase, which serialises the pipeline) and joined in registers.
 __device__ __forceinline__ i32x8_t join8(const bf16x8_t lo, const bf16x8_t hi) {
   return __builtin_shufflevector(__builtin_bit_cast(i32x4_t, lo), __builtin_bit_cast(i32x4_t, hi), 0, 1, 2, 3, 4, 5, 6, 7);
@@ -92,11 +94,11 @@ __device__ __forceinline__ void read_a(Frags8& f, const lds_byte_ptr (&ad)[4], i
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
-      f.a[mt][ks] = join8(*reinterpret_cast<lds_frag_ptr>(ad[ks] + off + mt * 32 * 128), *reinterpret_cast<lds_frag_ptr>(ad[ks] + off + mt * 32 * 128 + 16));
+      f.a[mt][ks] = join8(*reinterpret_cast<lds_frag_ptr>(ad[ks] + off + mt * 32 * 128), *reinterpret_cast<lds_frag_ptr>(ad[ks + 2] + off + mt * 32 * 128));
 }
 __device__ __forceinline__ void read_b(i32x8_t (&b)[2], const lds_byte_ptr (&ad)[4], int off) {
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) b[ks] = join8(*reinterpret_cast<lds_frag_ptr>(ad[ks] + off), *reinterpret_cast<lds_frag_ptr>(ad[ks] + off + 16));
+  for (int ks = 0; ks < 2; ++ks) b[ks] = join8(*reinterpret_cast<lds_frag_ptr>(ad[ks] + off), *reinterpret_cast<lds_frag_ptr>(ad[ks + 2] + off));
 }
 template <int V>
 __device__ __forceinline__ void mma_quadrant(f32x16_t (&acc)[2], const bf16x8_t (&a)[2][4], const bf16x8_t (&b)[4],
@@ -169,9 +171,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict_
   // Source address = buffer descriptor over the tile's 256-row band + one 32-bit per-lane byte offset (VGPR) + a
   // wave-uniform byte offset (SGPR): no 64-bit per-lane pointers in the loop.
   const int lrow = lane >> 3;
-  // e4m3: the swizzle moves 32-byte chunk PAIRS only (a lane's fragment = 32 contiguous bytes, pair P at P ^ ((r>>1)&3)),
-  // so that the two halves of a pair keep their order for every row (A and B fragments must pair byte for byte)
-  const int sw_src = F8 ? 2 * (((w & 1) * 4 + (lrow >> 1)) & 3) : ((w & 1) * 4 + (lrow >> 1)) & 7;
+  // (e4m3 uses the same 16-byte swizzle: a lane's fragment is two logical chunks L, L + 1, fetched from wherever each lies)
+  const int sw_src = ((w & 1) * 4 + (lrow >> 1)) & 7;
   const int gkb = ((lane & 7) ^ sw_src) * 16;                       // source chunk, bytes
   const uint32_t a_lane = (uint32_t)((w * 8 + lrow) * lda * ESZ + gkb);
   const uint32_t b_lane = (uint32_t)(((w >> 2) * 64 + (w & 3) * 8 + lrow) * ldb * ESZ + gkb);
@@ -214,7 +215,8 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict_
   lds_byte_ptr a_ad0[4], a_ad1[4], b_ad0[4], b_ad1[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    const int ko = F8 ? (lane & 31) * 128 + ((((ks & 1) * 4 + kh * 2) ^ (2 * (fsw & 3))) << 4)      // ks >= 2 unused
+    // e4m3: ks = 0, 1 -> first chunk of 64-wide step ks (logical chunk (ks&1)*4 + 2 kh), ks = 2, 3 -> its second chunk (+1)
+    const int ko = F8 ? (lane & 31) * 128 + (((((ks & 1) * 4 + kh * 2) + (ks >> 1)) ^ fsw) << 4)
                       : (lane & 31) * 128 + (((ks * 2 + kh) ^ fsw) << 4);
     a_ad0[ks] = lds0 + wr * 64 * 128 + ko;
     b_ad0[ks] = lds0 + wc * 32 * 128 + ko;
