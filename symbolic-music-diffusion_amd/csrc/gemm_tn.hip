@@ -130,8 +130,11 @@ struct TnGroupArgs {
 
 // NS LDS K-tile buffers: 2 (64 KiB, two workgroups per CU) or 4 (128 KiB; three K-tiles in flight -- for the
 // 128-wide weights every workgroup runs few MFMAs per K-tile and a 2-deep pipeline waits on the DMA latency).
-template <int NS>
-__global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
+// NW = waves that issue the LDS-DMA: 4 (the MFMA waves themselves) or 8 -- four extra LOADER waves that only stage their
+// share of every K-tile and take part in the barriers.  The per-CU LDS-DMA rate follows the number of waves issuing it
+// (a lone 4-wave workgroup reaches ~20 GB/s, the 8-wave kernels ~42), and CU-exclusive wgrad workgroups are alone on a CU.
+template <int NS, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];
 
   int gi = 0;
@@ -148,8 +151,9 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wc = w & 1;
-  const bool do_bias = (a.bias_out != nullptr) && tk == 0 && wr == 0;     // wave-uniform
+  const bool mma = w < 4;                                                  // waves 4.. only load
+  const int wr = (w & 3) >> 1, wc = w & 1;
+  const bool do_bias = (a.bias_out != nullptr) && tk == 0 && wr == 0 && mma;     // wave-uniform
 
   // ---- DMA sources: wave w piece j covers LDS rows (w*4+j)*4 .. +4 ; 16 lanes per 256-B row.
   // LDS chunk (lane&15) of row r receives global chunk (lane&15) ^ ((r&3)<<2); r&3 == lane>>4.
@@ -159,18 +163,20 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
   // keep the 16-B read inside the row: columns past the end only feed discarded outputs
   xcol = xcol + 8 <= a.ldx ? xcol : 0;
   ycol = ycol + 8 <= a.ldy ? ycol : 0;
-  const int piece_row = w * 16 + (lane >> 4);     // + j*4
+  constexpr int RPW = BKM / NW;                   // K-tile rows staged per wave (16 or 8), in pieces of 4 rows
+  constexpr int NJ = RPW / 4;
+  const int piece_row = w * RPW + (lane >> 4);    // + j*4
 
   auto issue_tile = [&](int kt, int buf) {
-    unsigned char* base = smem + buf * BUF_BYTES + w * 4096;
+    unsigned char* base = smem + buf * BUF_BYTES + w * (RPW * 256);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int m = kt * BKM + piece_row + j * 4;
       const bf16_t* src = m < a.Mrows ? a.X + (size_t)m * a.ldx + xcol : a.zero_page + (lane & 15) * 8;
       glds16(src, base + j * 1024);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       const int m = kt * BKM + piece_row + j * 4;
       const bf16_t* src = m < a.Mrows ? a.dY + (size_t)m * a.ldy + ycol : a.zero_page + (lane & 15) * 8;
       glds16(src, base + TILE_BYTES + j * 1024);
@@ -214,17 +220,18 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
     if constexpr (NS == 2) {
       if (kt + 1 < kt_end) {
         issue_tile(kt + 1, wbuf);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     } else {
       const int nxt = kt + NS - 1;
       issue_tile(nxt < kt_end ? nxt : kt_end - 1, wbuf);
-      asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * 2 * NJ) : "memory");      // NS-1 tiles stay in flight
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if (mma) {
     const unsigned tb = lds_base + buf * BUF_BYTES + m_lane * 256;
     Frag8 af[2][2], bfr[2][2];       // two k-steps of fragments: one being multiplied, the next one arriving
 #define SMD_TN_MMA(S)                                                                           \
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
     SMD_TN_MMA(1)
 #undef SMD_TN_MMA
 #undef SMD_TN_ISSUE
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     buf = buf + 1 == NS ? 0 : buf + 1;
@@ -259,6 +267,7 @@ __global__ __launch_bounds__(256) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant tail requests
   __builtin_amdgcn_s_barrier();
+  if (!mma) return;                                    // loader waves are done (barriers only count live waves)
 
   // ---- destination of this block's partial: final buffers or its split's slab
   float* dst = a.out;
@@ -478,6 +487,15 @@ static int smd_tn_pick_split(int tiles, int total_kt, int max_split) {
   return best;
 }
 
+// CU-exclusive launch: four MFMA waves + four loader waves (tn128_loader_waves = 0: the four MFMA waves load themselves)
+#define SMD_TN_EXCL_LAUNCH(tiles_, nsplit_, ga_)                                                                                \
+  do {                                                                                                                          \
+    if (smd_tuning_get("tn128_loader_waves"))                                                                                   \
+      hipLaunchKernelGGL((gemm_tn_128x128_kernel<4, 8>), dim3(tiles_, nsplit_), dim3(512), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga_); \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((gemm_tn_128x128_kernel<4, 4>), dim3(tiles_, nsplit_), dim3(256), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga_); \
+  } while (0)
+
 size_t gemm_tn_slab_elems() { return (size_t)4 * 2048 * 2048 + (size_t)1024 * 1024; }
 
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
@@ -515,8 +533,8 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t.slab; a.slab_stride = stride;
     a.tiles_n = tiles_n; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t.zero_page;
     if (smd_tuning_get("tn_exclusive_cu") || (per >= 6 && smd_tuning_get("gemm_tn_deep")))
-      hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga);
-    else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
+      SMD_TN_EXCL_LAUNCH(tiles, nsplit, ga);
+    else hipLaunchKernelGGL((gemm_tn_128x128_kernel<2, 4>), dim3(tiles, nsplit), dim3(256), 0, st, ga);
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
       RedGroupArgs ra;
@@ -594,8 +612,8 @@ int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st) {
       slab_off += (size_t)nsplit * stride;
     }
     // tn_exclusive_cu (default): the 4-buffer instantiation padded to the CU's whole LDS, see smd_tn_pad_bytes()
-    if (smd_tuning_get("tn_exclusive_cu")) hipLaunchKernelGGL(gemm_tn_128x128_kernel<4>, dim3(tiles, nsplit), dim3(256), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga);
-    else hipLaunchKernelGGL(gemm_tn_128x128_kernel<2>, dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    if (smd_tuning_get("tn_exclusive_cu")) SMD_TN_EXCL_LAUNCH(tiles, nsplit, ga);
+    else hipLaunchKernelGGL((gemm_tn_128x128_kernel<2, 4>), dim3(tiles, nsplit), dim3(256), 0, st, ga);
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ra);
