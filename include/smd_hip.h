@@ -178,7 +178,13 @@ int smd_langevin_step(const smd_langevin_io* io, int B, int S, int C, void* stre
  *               LDS-using workgroup shares their CU (small LayerNorm-backward workgroups that did lost bitwise
  *               repeatability), 0 = unpadded (a few % faster, not repeatable);
  * "gemm_tn256": 1 = 2048-wide weight gradients use the 256x256 8-phase kernel (default), 0 = 128-wide tiles,
- *               2 = also on small grids (tests). */
+ *               2 = also on small grids (tests);
+ * "tn_exclusive_cu": 1 (default) = every weight-gradient workgroup is padded to the CU's whole LDS so that nothing shares
+ *               its CU (required for bitwise-repeatable training with the side stream);
+ * "tn_split_model": 1 = split-K of the 128-wide weight gradients chosen for whole rounds of 256 workgroups;
+ * "tn128_loader_waves": 1 = the CU-exclusive 128-wide weight-gradient kernel runs four extra waves that only issue LDS-DMA;
+ * further keys ("ln_bwd_wide", "ln_fwd_wide", "ln_bwd_narrow", "gemm_nt_deep", "gemm_nt_kg", "mlp_variant", ...) select
+ * between equivalent kernels for A/B runs; unknown keys return < 0. */
 int smd_set_tuning(const char* key, int value);
 
 /* ---- e4m3 (OCP fp8) path: BASELINE config 5.  Operands are e4m3 bytes with one power-of-two (E8M0) scale per row,
