@@ -1,0 +1,87 @@
+// LDS-DMA rate of ONE workgroup per CU as a function of the number of waves issuing it and of the tiles each wave keeps
+// in flight (round 2 finding: a lone 4-wave workgroup streams ~20 GB/s into its LDS, 8-wave workgroups ~42 GB/s, and more
+// tiles in flight per wave change nothing -- profiles/README.md, gemm_tn.hip loader waves).  This probe isolates it:
+// no MFMA, no LDS reads; every workgroup streams its own contiguous slice of a large buffer through a ring in LDS.
+//   build: hipcc -O3 --offload-arch=gfx950 tools/dma_waves.hip -o tools/dma_waves     run: tools/dma_waves
+// NOT YET RUN ON HARDWARE when it was committed (the round's GPU budget was spent); it only cross-compiles.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// NW waves; each wave issues PIECES 1-KiB DMA instructions per tile (tile = NW * PIECES KiB) and keeps DEPTH tiles in flight
+template <int NW, int PIECES, int DEPTH>
+__global__ __launch_bounds__(64 * NW) void dma_stream(const unsigned char* __restrict__ src, size_t bytes_per_wg, int tiles,
+                                                     unsigned* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int TILE = NW * PIECES * 1024;
+  const unsigned char* base = src + (size_t)blockIdx.x * bytes_per_wg + (size_t)w * PIECES * 1024 + lane * 16;
+  auto issue = [&](int t, int buf) {
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p)
+      __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (size_t)t * TILE + p * 1024),
+                                       (lds_void_t*)(smem + buf * TILE + (w * PIECES + p) * 1024), 16, 0, 0);
+  };
+  for (int t = 0; t < DEPTH - 1 && t < tiles; ++t) issue(t, t);
+  int buf = 0, wbuf = DEPTH - 1;
+  for (int t = 0; t < tiles; ++t) {
+    const int nxt = t + DEPTH - 1;
+    issue(nxt < tiles ? nxt : tiles - 1, wbuf);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * PIECES) : "memory");
+    __builtin_amdgcn_s_barrier();          // the consumer phase of a GEMM would sit here
+    __builtin_amdgcn_s_barrier();
+    buf = buf + 1 == DEPTH ? 0 : buf + 1;
+    wbuf = wbuf + 1 == DEPTH ? 0 : wbuf + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (threadIdx.x == 0) sink[blockIdx.x] = *reinterpret_cast<unsigned*>(smem);      // keep the LDS writes observable
+}
+
+template <int NW, int PIECES, int DEPTH>
+static void run(const unsigned char* d_src, size_t total, unsigned* d_sink, const char* what) {
+  constexpr int TILE = NW * PIECES * 1024;
+  const int nwg = 256;
+  const size_t per = total / nwg / TILE * TILE;
+  const int tiles = (int)(per / TILE);
+  const size_t lds = (size_t)DEPTH * TILE;
+  if (lds > 160 * 1024) { printf("%-52s skipped (%zu KiB LDS)\n", what, lds / 1024); return; }
+  hipFuncSetAttribute((const void*)dma_stream<NW, PIECES, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((dma_stream<NW, PIECES, DEPTH>), dim3(nwg), dim3(64 * NW), lds, 0, d_src, per, tiles, d_sink);
+  hipEventRecord(e0);
+  const int reps = 5;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((dma_stream<NW, PIECES, DEPTH>), dim3(nwg), dim3(64 * NW), lds, 0, d_src, per, tiles, d_sink);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double gbs = (double)per * nwg * reps / (ms * 1e-3) / 1e9;
+  printf("%-52s %7.1f GB/s per CU  %6.2f TB/s chip   (%d KiB tiles, %zu KiB LDS)\n", what, gbs / nwg, gbs / 1e3, TILE / 1024, lds / 1024);
+}
+
+int main() {
+  const size_t total = (size_t)2 << 30;          // 2 GiB: every workgroup streams its own 8 MiB from HBM
+  unsigned char* d_src;
+  unsigned* d_sink;
+  if (hipMalloc(&d_src, total) != hipSuccess || hipMalloc(&d_sink, 4096) != hipSuccess) { printf("hipMalloc failed\n"); return 1; }
+  hipMemset(d_src, 1, total);
+  printf("one workgroup per CU (256 workgroups), contiguous 8 MiB per workgroup, global_load_lds 16 B per lane\n");
+  run<4, 8, 2>(d_src, total, d_sink, " 4 waves x 8 KiB per tile, 2 tiles deep");
+  run<4, 8, 4>(d_src, total, d_sink, " 4 waves x 8 KiB per tile, 4 tiles deep");
+  run<4, 4, 4>(d_src, total, d_sink, " 4 waves x 4 KiB per tile, 4 tiles deep");
+  run<8, 4, 2>(d_src, total, d_sink, " 8 waves x 4 KiB per tile, 2 tiles deep");
+  run<8, 4, 4>(d_src, total, d_sink, " 8 waves x 4 KiB per tile, 4 tiles deep");
+  run<8, 8, 2>(d_src, total, d_sink, " 8 waves x 8 KiB per tile, 2 tiles deep");
+  run<16, 2, 4>(d_src, total, d_sink, "16 waves x 2 KiB per tile, 4 tiles deep");
+  run<16, 4, 2>(d_src, total, d_sink, "16 waves x 4 KiB per tile, 2 tiles deep");
+  run<16, 4, 2>(d_src, total, d_sink, "16 waves x 4 KiB per tile, 2 tiles deep (repeat)");
+  hipFree(d_src); hipFree(d_sink);
+  return 0;
+}
