@@ -131,8 +131,8 @@ struct TnGroupArgs {
 // NS LDS K-tile buffers: 2 (64 KiB, two workgroups per CU) or 4 (128 KiB; three K-tiles in flight -- for the
 // 128-wide weights every workgroup runs few MFMAs per K-tile and a 2-deep pipeline waits on the DMA latency).
 // NW = waves that issue the LDS-DMA: 4 (the MFMA waves themselves) or 8 -- four extra LOADER waves that only stage their
-// share of every K-tile and take part in the barriers.  The per-CU LDS-DMA rate follows the number of waves issuing it
-// (a lone 4-wave workgroup reaches ~20 GB/s, the 8-wave kernels ~42), and CU-exclusive wgrad workgroups are alone on a CU.
+// share of every K-tile and take part in the barriers: DMA issue then no longer queues behind the MFMA waves' own phases
+// (+2.8 % train step; the raw HBM -> LDS rate itself does not depend on the wave count, tools/dma_waves.hip).
 template <int NS, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm_tn_128x128_kernel(TnGroupArgs ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF_BYTES];

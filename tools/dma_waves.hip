@@ -1,9 +1,8 @@
 // LDS-DMA rate of ONE workgroup per CU as a function of the number of waves issuing it and of the tiles each wave keeps
-// in flight (round 2 finding: a lone 4-wave workgroup streams ~20 GB/s into its LDS, 8-wave workgroups ~42 GB/s, and more
-// tiles in flight per wave change nothing -- profiles/README.md, gemm_tn.hip loader waves).  This probe isolates it:
-// no MFMA, no LDS reads; every workgroup streams its own contiguous slice of a large buffer through a ring in LDS.
+// in flight: no MFMA, no LDS reads; every workgroup streams its own contiguous 8 MiB of a 2 GiB buffer (HBM, single use)
+// through a ring in LDS.  Measured (profiles/r2q_dma_waves.txt): 23.3-23.6 GB/s per CU = 6.0 TB/s over the chip for 4, 8
+// and 16 waves and 2 or 4 tiles in flight alike -- the HBM roof of this path; wave count and depth are not the lever.
 //   build: hipcc -O3 --offload-arch=gfx950 tools/dma_waves.hip -o tools/dma_waves     run: tools/dma_waves
-// NOT YET RUN ON HARDWARE when it was committed (the round's GPU budget was spent); it only cross-compiles.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
