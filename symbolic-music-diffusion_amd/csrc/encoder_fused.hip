@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void mlp_block_fwd_kernel(MlpArgs a) {
       s = wave_sum(s);
       s2 = wave_sum(s2);
       const float mean = s * (1.0f / E_DIM);
-      const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      const float rstd = smd_ln_rstd(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
       bf16x2_t o;
       o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
       o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void mlp_block_fwd8_kernel(MlpArgs a) {
       s = wave_sum(s);
       s2 = wave_sum(s2);
       const float mean = s * (1.0f / E_DIM);
-      const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      const float rstd = smd_ln_rstd(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
       bf16x2_t o;
       o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
       o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void ln128_parts_kernel(const float* __restric
     float st[2] = {x.x + x.y, x.x * x.x + x.y * x.y};
     wave_allreduce_sum<2>(st);
     const float mean = st[0] * (1.0f / E_DIM);
-    const float rstd = rsqrtf(st[1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+    const float rstd = smd_ln_rstd(st[1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
     const float2 g2 = *reinterpret_cast<const float2*>(gamma + lane * 2), b2 = *reinterpret_cast<const float2*>(beta + lane * 2);
     bf16x2_t t;
     t[0] = f2bf((x.x - mean) * rstd * g2.x + b2.x);
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void ln128_bwd_parts_kernel(const float* __res
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float mean = st[2 * i] * (1.0f / E_DIM);
-    rs[i] = rsqrtf(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+    rs[i] = smd_ln_rstd(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
     xh[i].x = (xv[i].x - mean) * rs[i];
     xh[i].y = (xv[i].y - mean) * rs[i];
     Qx += dv[i].x; Qy += dv[i].y;
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < 8; ++i) {
       const int r = w * 8 + i;
       const float mean = st[2 * i] * (1.0f / E_DIM);
-      const float rstd = rsqrtf(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      const float rstd = smd_ln_rstd(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
       bf16x2_t o;
       o[0] = f2bf((x[i].x - mean) * rstd * g2.x + b2v.x);
       o[1] = f2bf((x[i].y - mean) * rstd * g2.y + b2v.y);
@@ -1228,7 +1228,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) { s += stt[(ww * S_TOK + l31) * 2]; s2 += stt[(ww * S_TOK + l31) * 2 + 1]; }
     const float mean = s * (1.0f / E_DIM);
-    const float rstd = rsqrtf(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
+    const float rstd = smd_ln_rstd(s2 * (1.0f / E_DIM) - mean * mean + LN_EPS);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int f = w * 32 + 4 * kh + 8 * g;

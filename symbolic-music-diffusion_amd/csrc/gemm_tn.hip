@@ -461,7 +461,7 @@ int launch_colsum_bf16(const bf16_t* dY, int ldy, int rows, int cols, float* out
 
 // room for 4 split partials of a 2048x2048 weight (gemm_tn256) + bias partial rows
 int smd_tn_pad_bytes(int static_lds_bytes) {
-  if (!smd_tuning_get("tn_exclusive_cu")) return 0;
+  if (smd_tuning_get("tn_exclusive_cu") != 1) return 0;      // 2: the exclusive launch's kernels WITHOUT the pad (A/B)
   const int pad = 160 * 1024 - static_lds_bytes;
   return pad > 0 ? pad : 0;
 }

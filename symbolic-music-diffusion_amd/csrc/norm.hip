@@ -97,7 +97,7 @@ __device__ __forceinline__ void row_stats(const float (&x)[RowLayout<D>::PER_LAN
   s2 = wave_sum(s2);
   mean = s * (1.0f / D);
   const float var = s2 * (1.0f / D) - mean * mean;
-  rstd = rsqrtf(var + LN_EPS);
+  rstd = smd_ln_rstd(var + LN_EPS);
 }
 
 // ------------------------------------------------------------------------------ forward
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, i
     s = wave_sum(s);
     sq = wave_sum(sq);
     const float mean = s * (1.0f / D);
-    const float rstd = rsqrtf(sq * (1.0f / D) - mean * mean + LN_EPS);
+    const float rstd = smd_ln_rstd(sq * (1.0f / D) - mean * mean + LN_EPS);
     bf16_t* orow = a.out + (size_t)row * D;
     float yk[F8 ? NV : 1][4];
     float amax = 0.f;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
     s = wave_sum(s);
     sq = wave_sum(sq);
     const float mean = s * (1.0f / D);
-    const float rstd = rsqrtf(sq * (1.0f / D) - mean * mean + LN_EPS);
+    const float rstd = smd_ln_rstd(sq * (1.0f / D) - mean * mean + LN_EPS);
     fence_x();
     // pass 2: column sums P, Q and the row sums
     float s1 = 0.f, s2 = 0.f;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
     for (int i = 0; i < 8; ++i) { s += x[it][i]; s2 += x[it][i] * x[it][i]; }
     s = sum16(s); s2 = sum16(s2);
     const float mean = s * (1.0f / D);
-    const float rstd = rsqrtf(s2 * (1.0f / D) - mean * mean + LN_EPS);
+    const float rstd = smd_ln_rstd(s2 * (1.0f / D) - mean * mean + LN_EPS);
     float dxh[8], xh[8], t1 = 0.f, t2 = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

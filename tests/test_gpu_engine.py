@@ -236,3 +236,48 @@ def test_sample_api_full_walk_small():
     assert hit == [0] + list(range(2, 41))
     with pytest.raises(ValueError):
         N.sample(model, BETAS, N.PRNGKey(1), (32, 42), num_samples=4, sampling="hmc")
+
+
+@pytest.mark.parametrize("rng_impl", ["philox", "threefry"])
+@pytest.mark.parametrize("infill", [False, True])
+def test_two_chain_sampler_equals_one_chain_and_eager(rng_impl, infill, monkeypatch):
+    """The production default walks a graphed batch of >= 128 sequences as TWO concurrent half-batch chains (own engine
+    handle, stream, hipGraph, nt256_min_tiles = 128 each).  Draws are keyed by the global sample index, infill slices and
+    the collection / metrics are concatenated per chain, every handle advances its own device-side t: the result must be
+    the one-chain walk's and the eager walk's (bitwise where the kernel selection is the same, else within the
+    GEMM-variant rounding), for Philox and jax.random streams, with and without infill."""
+    import smd_amd.ncsn as N
+    _, _, model = make(C=512, L=2, K=1)
+    B = 128
+    key = N.make_key(5, rng_impl)
+    g = torch.Generator().manual_seed(77)
+    init = torch.randn(B, 32, 512, generator=g)
+    kw = {}
+    if infill:
+        mask = torch.zeros(B, 32, 512)
+        mask[:, 8:24] = 1.0                                        # the middle 16 of 32 latents (sample_ncsn.py:189-243)
+        kw = dict(infill=True, infill_samples=torch.clamp(0.25 * torch.randn(B, 32, 512, generator=g), -1, 1), infill_masks=mask)
+    T_STOP = 972                                                    # 28 iterations: the t = 975 snapshot (slot 2) is taken
+
+    def walk(chains, graph):
+        monkeypatch.setenv("SMD_SAMPLER_CHAINS", str(chains))
+        assert N._sampler_chains(model, B, graph) == (2 if (chains == 2 and graph) else 1)
+        return N.diffusion_dynamics(key, model, BETAS, init, t_stop=T_STOP, use_graph=graph, **kw)
+
+    x2, c2, m2 = walk(2, True)
+    x1, c1, m1 = walk(1, True)
+    xe, ce, me = walk(1, False)
+    assert torch.equal(x1, xe) and torch.equal(c1, ce) and torch.equal(m1, me)      # one chain: replay == eager, bitwise
+    assert float(c2[2].abs().max()) > 0 and float(c2[1].abs().max()) == 0 and float(c2[3:].abs().max()) == 0
+    assert torch.equal(c2[0], c1[0])
+    # the half-batch handles may select other GEMM variants (64 tiles per chain vs 128): bf16 rounding differences only
+    assert rel(x2, x1) < 5e-3, rel(x2, x1)
+    assert rel(c2[2], c1[2]) < 5e-3
+    rows = slice(0, 1000 - T_STOP)
+    assert rel(m2[:, rows, 0], m1[:, rows, 0]) < 5e-3
+    assert torch.equal(m2[2], m1[2])                                                # the alpha_prod row is table data
+    # every sample of the second chain really advanced (its own t counter and its own slice of the noise stream)
+    assert float((x2[B // 2:] - init[B // 2:].cuda()).abs().max()) > 0
+    if infill:
+        m = kw["infill_masks"].cuda().bool()
+        assert rel(x2[m], x1[m]) < 5e-3
