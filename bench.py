@@ -148,6 +148,17 @@ def cpu_baseline(cfg_name: str, batch: int):
             "train_steps_per_sec": round(scale / t_train, 5), "sample_steps_per_sec": round(scale / t_sample, 5)}
 
 
+_CHAIN_STREAMS = {}     # device -> the two chain streams, created once per process: HIP maps streams onto a few hardware
+                        # queues round-robin, and a LATER pair of fresh streams can land on one queue (the two chains then
+                        # serialise: measured 2.2x per sample step on the second workload of a process)
+
+
+def chain_streams(torch, dev, n):
+    if dev not in _CHAIN_STREAMS:
+        _CHAIN_STREAMS[dev] = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    return _CHAIN_STREAMS[dev][:n]
+
+
 class Workload:
     """One configuration's resident state: model + optimiser + the sampler chains, and the two timed loops."""
 
@@ -205,7 +216,7 @@ class Workload:
             eng.init_state(xc, 4321, rank * B + c * hB)
             ch = dict(eng=eng, x=xc, t_ptr=torch.tensor([999], dtype=torch.int32, device=dev),
                       metrics=torch.zeros(1000, hB, 3, device=dev), coll=torch.zeros(41, hB, 32, 512, device=dev),
-                      graph=None, stream=torch.cuda.Stream(device=dev) if nchains > 1 else None)
+                      graph=None, stream=chain_streams(torch, dev, nchains)[c] if nchains > 1 else None)
             io = lib.SampleIO()
             io.x, io.t_ptr = xc.data_ptr(), ch["t_ptr"].data_ptr()
             io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B + c * hB

@@ -105,6 +105,11 @@ int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labe
  * a real uniform used_alpha in [alphas_prod[T], 1).  used_alphas ([B] device floats, or NULL) replaces the label -> alpha
  * lookup of the following smd_engine_loss_backward calls (parity mode: the reference's own jax.random.uniform draws). */
 int smd_engine_set_used_alphas(smd_engine* e, const float* used_alphas);
+/* Debugging aid (tools/det_first_diff.py): with a buffer of smd_engine_debug_snapshot_bytes() bytes set, the encoder backward
+ * copies the shared per-layer gradient buffers (da2 partial tiles, dh, dA_E, dh) behind each of its kernels into it, so two
+ * identical steps can be compared kernel by kernel; NULL switches it off (the default). */
+int64_t smd_engine_debug_snapshot_bytes(const smd_engine* e);
+int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes);
 const float* smd_engine_loss_per_sample(const smd_engine* e);   /* [B] device pointer */
 const float* smd_engine_pred(const smd_engine* e);              /* [B*S][C] device pointer */
 
@@ -174,13 +179,16 @@ int smd_langevin_step(const smd_langevin_io* io, int B, int S, int C, void* stre
  * "gemm_nt256_variant": schedule variant of that kernel, 0 (default) .. 3, all computing the same result; the
  *               ablation variants used by tools/kbench.py exist only in a -DSMD_ABLATIONS build;
  * "ln_bwd_narrow": 1 (default) = the 128-wide LayerNorm backward runs on the 16-lanes-per-row kernel, 0 = one row per wave;
- * "tn_exclusive_cu": 1 (default) = weight-gradient GEMM workgroups are padded to a CU's whole LDS so that no other
- *               LDS-using workgroup shares their CU (small LayerNorm-backward workgroups that did lost bitwise
- *               repeatability), 0 = unpadded (a few % faster, not repeatable);
+ * "tn_exclusive_cu": which 128-wide weight-gradient kernel the side stream runs and whether its workgroups own their CU:
+ *               2 (default) = the four-buffer kernel (+ loader waves), unpadded: small-LDS workgroups of the main stream may
+ *               share its CU (bitwise repeatable: 0 of 1499 repeated steps differ); 1 = the same kernels
+ *               padded to the CU's whole LDS so that nothing shares their CU (the round-2 default, 2 % slower);
+ *               0 = the two-buffer kernel, unpadded -- kept for the A/B only: with it on their CU the 128-wide LayerNorm
+ *               backward kernels intermittently read a stale register in lanes 48..63 (not repeatable);
+ * "tn_mode":    0 (default) = as "tn_exclusive_cu" says; NS*100 + NW*10 + pad picks buffers / issuing waves / pad (0 none,
+ *               1 whole CU, 2 96 KiB) of that kernel explicitly (tools/r3_det_modes.sh);
  * "gemm_tn256": 1 = 2048-wide weight gradients use the 256x256 8-phase kernel (default), 0 = 128-wide tiles,
  *               2 = also on small grids (tests);
- * "tn_exclusive_cu": 1 (default) = every weight-gradient workgroup is padded to the CU's whole LDS so that nothing shares
- *               its CU (required for bitwise-repeatable training with the side stream);
  * "tn_split_model": 1 = split-K of the 128-wide weight gradients chosen for whole rounds of 256 workgroups;
  * "tn128_loader_waves": 1 = the CU-exclusive 128-wide weight-gradient kernel runs four extra waves that only issue LDS-DMA;
  * further keys ("ln_bwd_wide", "ln_fwd_wide", "ln_bwd_narrow", "gemm_nt_deep", "gemm_nt_kg", "mlp_variant", ...) select

@@ -130,6 +130,11 @@ int smd_engine_set_used_alphas(smd_engine* e, const float* used_alphas) {
   e->impl.set_used_alphas(used_alphas);
   return 0;
 }
+int64_t smd_engine_debug_snapshot_bytes(const smd_engine* e) { return e ? e->impl.debug_snapshot_bytes() : -1; }
+int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes) {
+  NEED(e);
+  return e->impl.set_debug_snapshots(buf, bytes);
+}
 const float* smd_engine_loss_per_sample(const smd_engine* e) { return e ? e->impl.loss_per_sample() : nullptr; }
 const float* smd_engine_pred(const smd_engine* e) { return e ? e->impl.pred() : nullptr; }
 

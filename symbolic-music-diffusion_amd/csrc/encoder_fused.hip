@@ -895,6 +895,7 @@ __global__ __launch_bounds__(256) void ln128_bwd_parts_kernel(const float* __res
     if constexpr (DRES) rv[i] = *reinterpret_cast<const float2*>(dres + o);
     else rv[i] = make_float2(0.f, 0.f);
   }
+  smd_load_settle();
   float st[16];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { st[2 * i] = xv[i].x + xv[i].y; st[2 * i + 1] = xv[i].x * xv[i].x + xv[i].y * xv[i].y; }

@@ -119,6 +119,13 @@ class SmdEngine {
   // gradient are 0.5 sum (sigma score + eps)^2 and its batch mean's derivative.
   int loss_kind = 0;
   void set_used_alphas(const float* a) { used_alphas_ = a; }
+  // Debugging aid (tools/det_first_diff.py): when a buffer is set, backward_stem copies the state of the SHARED, per-layer
+  // overwritten gradient buffers behind every encoder-layer kernel into it (per layer, in execution order: da2 partial
+  // tiles after mlp_hs_bwd, dh after the ln2 backward, dA_E after attn_block_bwd, dh after the ln1 backward; plus the layer's
+  // incoming dh and its saved h_mid), so that two
+  // identical steps can be compared kernel by kernel.  bytes >= debug_snapshot_bytes(); null switches it off.
+  int64_t debug_snapshot_bytes() const { return (int64_t)d_.num_layers * 34 * rows() * d_.embed_channels; }
+  int set_debug_snapshots(void* buf, int64_t bytes);
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   // The 2048-wide trunk y (models/ncsn.py:171-176) lives in bf16 instead of fp32: the residual operand and the output of
   // every fc2 GEMM and the LayerNorm inputs (forward and backward) shrink by half (-64 MB per DenseResBlock; the fp32
@@ -184,6 +191,7 @@ class SmdEngine {
   float *grads_ = nullptr, *m_ = nullptr, *v_ = nullptr, *ema_ = nullptr, *metrics_ = nullptr;
   uint32_t* step_ptr_ = nullptr;
   const float* used_alphas_ = nullptr;
+  char* dbg_snap_ = nullptr;
   const float* coef_ = nullptr;
   const float* sqrt_ap_ = nullptr;
   const float* alphas_prod_ext_ = nullptr;

@@ -730,9 +730,24 @@ int SmdEngine::backward_head(hipStream_t st) {
   return 0;
 }
 
+int SmdEngine::set_debug_snapshots(void* buf, int64_t bytes) {
+  SMD_ARG_CHECK(!buf || (batch_ > 0 && bytes >= debug_snapshot_bytes()), "set_debug_snapshots: %lld bytes given, %lld needed",
+                (long long)bytes, (long long)(batch_ > 0 ? debug_snapshot_bytes() : -1));
+  dbg_snap_ = reinterpret_cast<char*>(buf);
+  return 0;
+}
+
 int SmdEngine::backward_stem(hipStream_t st) {
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims;
   const int R = rows(), B = batch_;
+  // debug snapshots (set_debug_snapshots): segment `seg` of layer l <- src, stream-ordered behind the kernel that wrote it
+  const size_t RE = (size_t)R * E;
+  auto snap = [&](int l, int seg, const void* src) {
+    if (!dbg_snap_) return;
+    static const size_t off[6] = {0, 16, 20, 22, 26, 30}, len[6] = {16, 4, 2, 4, 4, 4};        // in units of R*E bytes
+    char* dst = dbg_snap_ + ((size_t)(d_.num_layers - 1 - l) * 34 + off[seg]) * RE;
+    (void)hipMemcpyAsync(dst, src, len[seg] * RE, hipMemcpyDeviceToDevice, st);
+  };
   if (d_.arch != 0) {
     return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dyb[0], M, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
   }
@@ -742,11 +757,14 @@ int SmdEngine::backward_stem(hipStream_t st) {
     bf16_t* dh_in = W.dhb[2 * l + 2];
     bf16_t* dh_mid = W.dhb[2 * l + 1];
     bf16_t* dh_out = W.dhb[2 * l];
+    snap(l, 4, W.dh);
+    snap(l, 5, W.h_mid[l]);
     if (hs_train_) {
       // fused backward with the hidden activations recomputed from a2: writes u and dz1 (wgrad operands) and four
       // partial tiles of da2; the ln2 backward sums them (launch-boundary reduce)
       RC(launch_mlp_block_bwd_hs(W.a2[l], dh_in, R, wpack_ + p.fc1.Wt_off, wpack_ + p.fc2.W_off, wpack_ + p.fc1.W_off, P(p.fc1.b_off),
                                  M, W.u[l], W.dz1[l], W.mlp_part, st));
+      snap(l, 0, W.mlp_part);
       RC(wgrad(p.fc2, W.u[l], M, dh_in, E, R, true, st));
       RC(wgrad(p.fc1, W.a2[l], E, W.dz1[l], M, R, true, st));
       const size_t need = (size_t)(R / 32) * 2 * E;
@@ -757,6 +775,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       LnReduceEntry en;
       en.partial = partial; en.ngroups = R / 32; en.D = E; en.dgamma = G(p.ln2.g_off); en.dbeta = G(p.ln2.b_off); en.block_start = 0;
       ln_pending_.push_back(en);
+      snap(l, 1, W.dh);
     } else {
       // mlp.fc2: h_out = u W2 + b + h_mid ; dz1 = (dh W2^T) * gelu'(z1)
       RC(dense_bwd(p.fc2, W.u[l], M, dh_in, E, R, W.dz1[l], M, W.z1[l], M, SMD_AUX_GELU_GRAD, st, true));
@@ -772,6 +791,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       RC(wgrad(p.out, W.o[l], E, dh_mid, E, R, true, st));
       RC(launch_attn_block_bwd(dh_mid, W.qkv[l], wpack_ + p.out.W_off, wpack_ + p.qkv.W_off, W.dqkv[l], W.dA_E, R,
                                d_.num_heads, st));
+      snap(l, 2, W.dA_E);
       RC(wgrad(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, true, st));
     } else {
       RC(dense_bwd(p.out, W.o[l], E, dh_mid, E, R, W.do_, E, nullptr, 0, SMD_AUX_NONE, st, true));
@@ -784,6 +804,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_out;
       b.dgamma = G(p.ln1.g_off); b.dbeta = G(p.ln1.b_off);
       RC(ln_bwd(b, st));
+      snap(l, 3, W.dh);
     }
     // this layer's four 128-wide wgrads as one side-stream launch; layer 0's wait for in_proj's (the 4-tile in_proj
     // problem alone was a 17 us launch + a reduce of its own at the very end of the step)

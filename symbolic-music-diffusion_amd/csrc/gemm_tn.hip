@@ -487,14 +487,29 @@ static int smd_tn_pick_split(int tiles, int total_kt, int max_split) {
   return best;
 }
 
-// CU-exclusive launch: four MFMA waves + four loader waves (tn128_loader_waves = 0: the four MFMA waves load themselves)
-#define SMD_TN_EXCL_LAUNCH(tiles_, nsplit_, ga_)                                                                                \
-  do {                                                                                                                          \
-    if (smd_tuning_get("tn128_loader_waves"))                                                                                   \
-      hipLaunchKernelGGL((gemm_tn_128x128_kernel<4, 8>), dim3(tiles_, nsplit_), dim3(512), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga_); \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((gemm_tn_128x128_kernel<4, 4>), dim3(tiles_, nsplit_), dim3(256), smd_tn_pad_bytes(4 * BUF_BYTES), st, ga_); \
-  } while (0)
+// CU-exclusive launch: four MFMA waves + four loader waves (tn128_loader_waves = 0: the four MFMA waves load themselves).
+// Knob "tn_mode" (A/B experiments) overrides the choice: NS*100 + NW*10 + pad, pad 0 = none, 1 = fill the
+// CU's 160 KiB, 2 = pad the workgroup to 96 KiB (one wgrad workgroup per CU, small-LDS workgroups may still share it).
+static int smd_tn_launch_128(int tiles, int nsplit, const TnGroupArgs& ga, bool exclusive_default, hipStream_t st) {
+  int mode = smd_tuning_get("tn_mode");
+  if (!mode) {
+    if (exclusive_default) mode = 400 + (smd_tuning_get("tn128_loader_waves") ? 80 : 40) + (smd_tuning_get("tn_exclusive_cu") == 1 ? 1 : 0);
+    else mode = 240;
+  }
+  const int ns = mode / 100, nw = (mode / 10) % 10, padc = mode % 10;
+  const int lds = ns * BUF_BYTES;
+  int pad = 0;
+  if (padc == 1) pad = 160 * 1024 - lds;
+  else if (padc == 2) pad = 96 * 1024 - lds;
+  if (pad < 0) pad = 0;
+  const dim3 grid(tiles, nsplit);
+  if (ns == 2 && nw == 4) hipLaunchKernelGGL((gemm_tn_128x128_kernel<2, 4>), grid, dim3(256), pad, st, ga);
+  else if (ns == 2 && nw == 8) hipLaunchKernelGGL((gemm_tn_128x128_kernel<2, 8>), grid, dim3(512), pad, st, ga);
+  else if (ns == 4 && nw == 4) hipLaunchKernelGGL((gemm_tn_128x128_kernel<4, 4>), grid, dim3(256), pad, st, ga);
+  else if (ns == 4 && nw == 8) hipLaunchKernelGGL((gemm_tn_128x128_kernel<4, 8>), grid, dim3(512), pad, st, ga);
+  else { smd_set_error("gemm_tn: tn_mode=%d names no instantiation", mode); return -1; }
+  return 0;
+}
 
 size_t gemm_tn_slab_elems() { return (size_t)4 * 2048 * 2048 + (size_t)1024 * 1024; }
 
@@ -532,9 +547,7 @@ int launch_gemm_tn(const TnLaunch& t, hipStream_t st) {
     a.X = t.X; a.ldx = t.ldx; a.dY = t.dY; a.ldy = t.ldy; a.Mrows = t.Mrows; a.Kd = t.Kd; a.N = t.N;
     a.out = t.out; a.ldo = t.ldo; a.bias_out = t.bias_out; a.slab = t.slab; a.slab_stride = stride;
     a.tiles_n = tiles_n; a.ktiles_per_split = per; a.nsplit = nsplit; a.zero_page = t.zero_page;
-    if (smd_tuning_get("tn_exclusive_cu") || (per >= 6 && smd_tuning_get("gemm_tn_deep")))
-      SMD_TN_EXCL_LAUNCH(tiles, nsplit, ga);
-    else hipLaunchKernelGGL((gemm_tn_128x128_kernel<2, 4>), dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    if (int rc = smd_tn_launch_128(tiles, nsplit, ga, smd_tuning_get("tn_exclusive_cu") || (per >= 6 && smd_tuning_get("gemm_tn_deep")), st)) return rc;
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
       RedGroupArgs ra;
@@ -611,9 +624,8 @@ int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st) {
       blocks += (int)(((size_t)t.Kd * t.N + (t.bias_out ? t.N : 0) + 255) / 256);
       slab_off += (size_t)nsplit * stride;
     }
-    // tn_exclusive_cu (default): the 4-buffer instantiation padded to the CU's whole LDS, see smd_tn_pad_bytes()
-    if (smd_tuning_get("tn_exclusive_cu")) SMD_TN_EXCL_LAUNCH(tiles, nsplit, ga);
-    else hipLaunchKernelGGL((gemm_tn_128x128_kernel<2, 4>), dim3(tiles, nsplit), dim3(256), 0, st, ga);
+    // tn_exclusive_cu != 0 (default 2): the four-buffer instantiation (1: padded to the CU's whole LDS, see smd_tn_pad_bytes())
+    if (int rc = smd_tn_launch_128(tiles, nsplit, ga, smd_tuning_get("tn_exclusive_cu") != 0, st)) return rc;
     SMD_LAUNCH_CHECK();
     if (nsplit > 1) {
       hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, ra);

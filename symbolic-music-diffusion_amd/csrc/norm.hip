@@ -751,14 +751,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
       r[it][0] = t0.x; r[it][1] = t0.y; r[it][2] = t0.z; r[it][3] = t0.w; r[it][4] = t1.x; r[it][5] = t1.y; r[it][6] = t1.z; r[it][7] = t1.w;
     }
   }
-  // all-reduce over the 16 lanes of a row with DPP (one DPP "row" == 16 lanes): xor-1 / xor-2 inside the quad, then
-  // half-mirror (quad pairs) and mirror (row halves); every step adds two commuting operands, so all 16 lanes end
-  // with the bitwise identical sum.  No ds_bpermute: the LDS crossbar is shared with co-resident workgroups.
+  smd_load_settle();
+  // all-reduce over the 16 lanes of a row: four xor exchanges (__shfl_xor = ds_bpermute); every step adds two commuting
+  // operands, so all 16 lanes end with the bitwise identical sum.  Until round 3 these were DPP row operations
+  // (quad_perm / row_half_mirror / row_mirror): a DPP instruction reads its source two wait states behind the VALU
+  // instruction that wrote it, and with a weight-gradient wave on the same SIMD that distance is not always enough --
+  // lanes 48..63 then take the stale register.  SMD_NARROW_DPP=1 rebuilds the DPP form for the A/B.
+#ifndef SMD_NARROW_DPP
+#define SMD_NARROW_DPP 0
+#endif
   auto sum16 = [](float v) {
+#if SMD_NARROW_DPP
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
     v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+#else
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+#endif
     return v;
   };
 #pragma unroll

@@ -46,15 +46,45 @@ __device__ __forceinline__ int smd_clamp_t(int t) { return t < 0 ? 0 : t; }
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
-// LayerNorm 1/sqrt(var + eps).  SMD_TRANS_SETTLE = N > 0 (experiment builds): the bare v_rsq_f32 (the
-// argument is >= 1e-6, never a denormal: same bits as rsqrtf) followed by N idle issue cycles before any VALU instruction may
-// read it -- tests whether consumers of a transcendental result one wait state behind it (what hipcc schedules) read a stale
-// register in lanes 48..63 when the SIMD is shared with a matrix-core wave.
+// Load-settle fence.  Placed between a kernel's up-front global loads and their first use: every load
+// has returned (vmcnt(0)) and SMD_LOAD_SETTLE x 16 further idle issue cycles have passed before any VALU instruction reads
+// a loaded register.  -1 = no fence (the compiler's counted vmcnt waits directly in front of the first use).
+#ifndef SMD_LOAD_SETTLE
+#define SMD_LOAD_SETTLE -1
+#endif
+__device__ __forceinline__ void smd_load_settle() {
+#if SMD_LOAD_SETTLE >= 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < SMD_LOAD_SETTLE; ++k) asm volatile("s_nop 15" ::: "memory");
+#endif
+}
+
+// LayerNorm 1/sqrt(var + eps) as the bare v_rsq_f32 (the argument is >= 1e-6, never a denormal: same bits as rsqrtf) with
+// EIGHT IDLE ISSUE CYCLES IN FRONT of it (default form, 98).  Round 3 found (profiles/r3_det_root_cause.txt):
+// with a two-buffer weight-gradient workgroup on the same CU, a v_rsq_f32 issued directly behind the VALU instruction that
+// writes its source operand -- what hipcc schedules -- intermittently reads the STALE register in lanes 48..63 (whole rows
+// of the 128-wide LayerNorm backward wrong by ~1e-2 with bit-identical inputs; 99 of 99 repeated steps differ).  Idle cycles
+// behind the instruction do not help (24 of 39), in front of it they do (0 of 499 on the encoder backward).
+// Other values are the experiment builds of that hunt: 0 rsqrtf(), -1 bare v_rsq_f32, N in 1..89 s_nop N-1 behind it, 90 + n
+// s_nop n in front, 99 s_nop 7 on both sides.
 #ifndef SMD_TRANS_SETTLE
-#define SMD_TRANS_SETTLE 0
+#define SMD_TRANS_SETTLE 98
 #endif
 __device__ __forceinline__ float smd_ln_rstd(float v) {
-#if SMD_TRANS_SETTLE > 0
+#if SMD_TRANS_SETTLE == 99
+  float r;                 // idle issue cycles on BOTH sides of the transcendental instruction
+  asm volatile("s_nop 7\n\tv_rsq_f32 %0, %1\n\ts_nop 7" : "=v"(r) : "v"(v));
+  return r;
+#elif SMD_TRANS_SETTLE >= 90 && SMD_TRANS_SETTLE <= 97
+  float r;                 // 90 + n: s_nop n in front, nothing behind
+  asm volatile("s_nop %2\n\tv_rsq_f32 %0, %1" : "=v"(r) : "v"(v), "n"(SMD_TRANS_SETTLE - 90));
+  return r;
+#elif SMD_TRANS_SETTLE == 98
+  float r;                 // idle issue cycles only in FRONT of it (its source operand was just written)
+  asm volatile("s_nop 7\n\tv_rsq_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(v));
+  return r;
+#elif SMD_TRANS_SETTLE > 0
   float r = __builtin_amdgcn_rsqf(v);
   asm volatile("s_nop %1" : "+v"(r) : "n"(SMD_TRANS_SETTLE - 1));
   return r;

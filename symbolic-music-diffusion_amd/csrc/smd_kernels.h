@@ -67,10 +67,11 @@ struct TnLaunch {
   int tr_path = 1;
 };
 size_t gemm_tn_slab_elems();
-// Weight-gradient GEMMs normally run on the engine's side stream next to the backward chain.  Small LayerNorm-backward
-// workgroups that SHARED A CU with their workgroups lost bitwise repeatability (established by
-// exclusion experiments, mechanism unknown), so by default (knob "tn_exclusive_cu" = 1) every weight-gradient workgroup is
-// launched with a dynamic-LDS pad that fills the CU's 160 KiB: no other LDS-using workgroup can be resident beside it.
+// Weight-gradient GEMMs normally run on the engine's side stream next to the backward chain.  With the TWO-buffer 128-wide
+// kernel on their CU, the small 128-wide LayerNorm-backward kernels lost bitwise repeatability (round 3, DESIGN.md section 6:
+// a v_rsq_f32 directly behind the VALU that writes its source reads the stale register in lanes 48..63).  Knob
+// "tn_exclusive_cu": 2 (default) = the four-buffer kernels, unpadded (0 of 1499 repeats differ with any LayerNorm build);
+// 1 = the same kernels with a dynamic-LDS pad that fills the CU's 160 KiB (round-2 default); 0 = the two-buffer kernel (A/B only).
 int smd_tn_pad_bytes(int static_lds_bytes);
 // 256x256 8-phase wgrad kernel (gemm_tn256.hip): plan returns nsplit (0 = not eligible)
 int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split);

@@ -78,6 +78,8 @@ _SIGS = {
     "smd_engine_loss_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_u32, c_u32, c_u32, C.c_float,
                                            C.c_int, c_void]),
     "smd_engine_set_used_alphas": (C.c_int, [c_void, c_void]),
+    "smd_engine_debug_snapshot_bytes": (c_i64, [c_void]),
+    "smd_engine_debug_snapshots": (C.c_int, [c_void, c_void, c_i64]),
     "smd_engine_loss_per_sample": (c_void, [c_void]),
     "smd_engine_pred": (c_void, [c_void]),
     "smd_engine_optimizer_step": (C.c_int, [c_void, C.POINTER(TrainHyper), c_void]),
