@@ -454,7 +454,8 @@ def collection_slot_for_t(T: int, t: int, table: Optional[np.ndarray] = None) ->
     hit = np.nonzero(table == image_idx)[0]
     if hit.size == 0:
         return -1
-    return int(np.sum(hit)) + 1   # sum(arange*mask)+1 (duplicates cannot occur for T>=40)
+    slot = int(np.sum(hit)) + 1   # sum(arange*mask)+1; T < 40 repeats entries and the sum can pass the last row:
+    return slot if slot <= COLLECTION_STEPS else -1   # index_update out of bounds is dropped by XLA's scatter
 
 
 def reverse_coefficients(betas: np.ndarray) -> Dict[str, np.ndarray]:
@@ -891,3 +892,80 @@ def jax_sampler_keys(ld_rng, T: int):
         infill_keys.append(infill_rng)
         noise_keys.append(noise_rng)
     return infill_keys, noise_keys
+
+
+# ----------------------------------------------------------------------------------
+# create_model's initial parameters (train_ncsn.py:193-203 -> flax.nn init_by_shape): the primitives, restated from the
+# flax 0.3.0 / jax 0.2.8 sources.  UNPINNED (no published vectors; tests/golden/make_jax_goldens.py dumps the real ones).
+# ----------------------------------------------------------------------------------
+def jax_fold_in(key, data: int):
+    """jax.random.fold_in(key, data) = threefry_2x32(key, PRNGKey(data)): one block on the counter pair (0, data)."""
+    y0, y1 = threefry2x32(key, np.array([0], np.uint32), np.array([int(data) & 0xFFFFFFFF], np.uint32))
+    return (y0[0], y1[0])
+
+
+def flax_fold_in_str(key, s: str):
+    """flax.nn.base._fold_in_str: fold the first four bytes (big endian) of sha1(s) into the key."""
+    import hashlib
+    return jax_fold_in(key, int.from_bytes(hashlib.sha1(s.encode("utf-8")).digest()[:4], byteorder="big"))
+
+
+def jax_truncated_normal(key, n: int, lower=-2.0, upper=2.0) -> np.ndarray:
+    """jax.random.truncated_normal (float32): u = uniform(key, minval=erf(lower/sqrt2), maxval=erf(upper/sqrt2));
+    sqrt(2) * erf_inv(u), clipped into the open interval (lower, upper)."""
+    f = np.float32
+    a, b = f(math.erf(lower / math.sqrt(2.0))), f(math.erf(upper / math.sqrt(2.0)))
+    u = jax_uniform(key, n, a, b)
+    out = (f(np.sqrt(2)) * erfinv_f32(u)).astype(np.float32)
+    return np.clip(out, np.nextafter(f(lower), f(np.inf), dtype=np.float32), np.nextafter(f(upper), f(-np.inf), dtype=np.float32))
+
+
+def jax_lecun_normal(key, shape) -> np.ndarray:
+    """jax.nn.initializers.lecun_normal()(key, (fan_in, fan_out)): truncated normal scaled to variance 1 / fan_in."""
+    f = np.float32
+    std = f(np.sqrt(f(1.0) / f(shape[0]), dtype=np.float32) / f(0.87962566103423978))
+    return (jax_truncated_normal(key, int(shape[0]) * int(shape[1])) * std).astype(np.float32).reshape(shape)
+
+
+def flax_param_key(model_rng, path):
+    """Key of the parameter at ``path`` = (child module names ..., parameter name): every level folds its name in."""
+    key = model_rng
+    for name in path:
+        key = flax_fold_in_str(key, name)
+    return key
+
+
+# ----------------------------------------------------------------------------------
+# --interpolate (sample_ncsn.py:245-310, 425-435): stochastic encode at the last noise level, 9-point lerp, decode
+# ----------------------------------------------------------------------------------
+def diffusion_stochastic_encoder(samples: np.ndarray, betas: np.ndarray, rng_seed: int) -> np.ndarray:
+    """sample_ncsn.py:245-266.  ``rng, noise_rng = split(PRNGKey(seed))`` and the noise is drawn from ``rng`` (:262-263, not
+    from noise_rng); alphas_prod[T] is one past the end and JAX clamps the gather to alphas_prod[T-1]."""
+    ap = alphas_cumprod(betas)
+    a_T = np.float32(ap[min(len(betas), len(ap) - 1)])
+    rng, _noise_rng = jax_split(jax_prngkey(rng_seed))
+    noise = jax_normal(rng, int(np.prod(samples.shape))).reshape(samples.shape)
+    mu = np.sqrt(a_T, dtype=np.float32) * samples.astype(np.float32)
+    sigma = np.sqrt(np.float32(1) - a_T, dtype=np.float32)
+    return (mu + sigma * noise).astype(np.float32)
+
+
+def interpolate_samples(model, betas: np.ndarray, real: np.ndarray, rng_seed: int, points: int = 9):
+    """sample_ncsn.py:425-435 + diffusion_decoder (:269-310): goals = roll(starts, 1); both encoded with the SAME seed (the same
+    noise); z_alpha = (1 - alpha) z_start + alpha z_goal for alpha in linspace(0, 1, 9); every z decoded by diffusion_dynamics
+    with the SAME ld_rng = split(PRNGKey(seed), 3)[1].  Returns (generated (9, N, ...), collection (9, 41, N, ...))."""
+    starts = np.asarray(real, dtype=np.float32)
+    goals = np.roll(starts, shift=1, axis=0)
+    zs, zg = diffusion_stochastic_encoder(starts, betas, rng_seed), diffusion_stochastic_encoder(goals, betas, rng_seed)
+    _rng, ld_rng, _model_rng = jax_split(jax_prngkey(rng_seed), 3)
+    T = len(betas)
+    _infill_keys, noise_keys = jax_sampler_keys(ld_rng, T)
+    n = int(np.prod(starts.shape))
+    zt = {T - 1 - i: torch.from_numpy(jax_normal(noise_keys[i], n).reshape(starts.shape)) for i in range(T)}
+    gens, colls = [], []
+    for alpha in np.linspace(0.0, 1.0, points):
+        z = ((1 - alpha) * zs + alpha * zg).astype(np.float32)
+        g, c, _m = diffusion_dynamics(model, betas, torch.from_numpy(z).double(), lambda t: zt[t].double())
+        gens.append(g)
+        colls.append(c)
+    return torch.stack(gens), torch.stack(colls)

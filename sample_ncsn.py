@@ -103,6 +103,26 @@ def diffusion_stochastic_encoder(samples, sigmas, rng, device="cuda:0", sample_o
     return np.sqrt(a_T) * samples + np.sqrt(1 - a_T) * noise
 
 
+def interpolate_samples(model, sigmas, real, lo, hi, rng, sample_seed, rng_impl, dev, use_graph=True, points=9):
+    """sample_ncsn.py:425-435 + diffusion_decoder (:269-310) for this rank's rows [lo, hi): goals = roll(starts, 1); both are
+    encoded with the same key (the same noise); every one of the 9 interpolated latents is decoded with the SAME
+    ld_rng = split(PRNGKey(sample_seed), 3)[1].  Returns (generated (9, n, ...), collection (9, 41, n, ...), collated metrics)."""
+    from smd_amd import ncsn
+    num = len(real)
+    starts = real[lo:hi]
+    goals = np.roll(real, shift=1, axis=0)[lo:hi]
+    zs, zg = (diffusion_stochastic_encoder(v, sigmas, rng, dev, lo, num) for v in (starts, goals))
+    _, ld_rng, _ = ncsn.split(ncsn.make_key(sample_seed, rng_impl), num=3)                 # :271-272 (the root key)
+    gens, colls = [], []
+    for i, alpha in enumerate(np.linspace(0.0, 1.0, points)):
+        g, c, ld = ncsn.diffusion_dynamics(ld_rng, model, sigmas, ((1 - alpha) * zs + alpha * zg).astype(np.float32),
+                                           use_graph=use_graph, sample_offset=lo, global_num_samples=num)
+        gens.append(g.cpu().numpy())
+        colls.append(c.cpu().numpy())
+        log.info("Generated samples %i out of %i", i, points)
+    return np.stack(gens), np.stack(colls), ncsn.collate_sampling_metrics(ld.cpu().numpy())
+
+
 def main(argv):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
     FLAGS = F.make_flags(include_sample=True)
@@ -158,19 +178,8 @@ def main(argv):
         generated, collection, ld_metrics = infill_samples(FLAGS, model, rng, samples, masks, sigmas, sample_offset=lo,
                                                            global_num_samples=num)
     elif FLAGS.interpolate:                                                 # :425-435
-        starts = real[lo:hi]
-        goals = np.roll(real, shift=1, axis=0)[lo:hi]
-        zs, zg = (diffusion_stochastic_encoder(v, sigmas, rng, dev, lo, num) for v in (starts, goals))
-        _, ld_rng, _ = ncsn.split(ncsn.make_key(FLAGS.sample_seed, FLAGS.rng_impl), num=3)     # :271-272 (the root key)
-        gens, colls = [], []
-        for i, alpha in enumerate(np.linspace(0.0, 1.0, 9)):
-            g, c, ld = ncsn.diffusion_dynamics(ld_rng, model, sigmas, ((1 - alpha) * zs + alpha * zg).astype(np.float32),
-                                               use_graph=FLAGS.graph, sample_offset=lo, global_num_samples=num)
-            gens.append(g.cpu().numpy())
-            colls.append(c.cpu().numpy())
-            log.info("Generated samples %i out of %i", i, 9)
-        generated, collection = np.stack(gens), np.stack(colls)
-        ld_metrics = ncsn.collate_sampling_metrics(ld.cpu().numpy())
+        generated, collection, ld_metrics = interpolate_samples(model, sigmas, real, lo, hi, rng, FLAGS.sample_seed, FLAGS.rng_impl,
+                                                                dev, FLAGS.graph)
     else:                                                                   # :437-439
         generated, collection, ld_metrics = generate_samples(FLAGS, model, rng, shape, hi - lo, sigmas, sample_offset=lo,
                                                              global_num_samples=num)

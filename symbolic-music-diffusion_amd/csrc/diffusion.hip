@@ -188,7 +188,8 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
   const float sqrt_recip = cf[0], sqrt_m1 = cf[1], mu1 = cf[2], mu2 = cf[3], sigma = cf[4];
   const float sqrt_ap = cf[6], sqrt_1m = cf[7];
   const bool noisy = t > 0;
-  const int slot = a.collection ? a.slot_table[t] : -1;
+  int slot = a.collection ? a.slot_table[t] : -1;
+  if (slot > 40) slot = -1;            // the collection has 41 rows (utils/ebm_utils.py:320-322); out-of-range scatters are dropped
   const uint32_t bglob = (uint32_t)b + a.sample_offset;
   const size_t sample_base = (size_t)b * a.S * a.C;
   const uint64_t tf_base = (uint64_t)bglob * a.S * a.C;       // this sample's first element in the global jax array

@@ -150,7 +150,15 @@ def create_model(rng: PRNGKey, input_shape, model_kwargs, batch_size=32, verbose
     accepts-and-ignores num_heads / num_mlp_layers like the reference's kwargs."""
     del batch_size
     cfg = config_from_kwargs(architecture, input_shape, model_kwargs, num_timesteps, dtype)
-    model = Model(cfg, device, seed=rng.seed & 0x7FFFFFFF)
+    if isinstance(rng, ThreefryKey):
+        # the reference's own initial weights: init_by_shape(model_rng) of the flax.nn module tree, every kernel
+        # lecun_normal() of its folded-in key (flax_init.py; with --rng_impl=threefry the step-0 state is the reference's)
+        from . import flax_init as _fi
+        model = Model(cfg, device, seed=None)
+        table = {name: shape for name, _off, shape in model.engine.tensor_table}
+        model.engine.load_named(_fi.init_params(cfg, rng, table))
+    else:
+        model = Model(cfg, device, seed=rng.seed & 0x7FFFFFFF)
     if verbose:
         from .train_utils import report_model
         report_model(model)

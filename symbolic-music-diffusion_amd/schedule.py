@@ -68,5 +68,8 @@ def collection_slot_table(T: int) -> np.ndarray:
     for t in range(T):
         hit = np.nonzero(table == (T - t + 1))[0]
         if hit.size:
-            slot[t] = int(np.sum(hit)) + 1
+            # short schedules (T < 40) repeat linspace entries and the summed index can pass the last row: the reference's
+            # jax.ops.index_update then scatters out of bounds, which XLA drops
+            s = int(np.sum(hit)) + 1
+            slot[t] = s if s <= COLLECTION_STEPS else -1
     return slot

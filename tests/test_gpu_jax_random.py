@@ -172,3 +172,57 @@ def test_sample_api_threefry_init_and_sharding():
     # 1000 steps; the rows ride in a different batch size, i.e. through different GEMM tilings (K-split order):
     # 1e-7 differences per step, amplified by the walk; a different stream would differ by O(1)
     assert float((half - gen[2:]).abs().max()) < 1e-2
+
+
+def test_create_model_with_a_threefry_key_draws_the_flax_initialiser():
+    """create_model(model_rng) with a jax.random key: the engine's step-0 weights are flax_init.init_params (the reference's
+    init_by_shape restated, train_ncsn.py:193-203), not the engine's own NumPy initialiser."""
+    import smd_amd.flax_init as FI
+    import smd_amd.jax_random as J
+    import smd_amd.ncsn as N
+    rng = J.PRNGKey(0)
+    _rng, model_rng, _s = N.split(rng, num=3)                                       # train_ncsn.py:318-319
+    kw = dict(num_layers=2, num_heads=8, num_mlp_layers=1, mlp_dims=2048)
+    model = N.create_model(model_rng, (32, 42), kw, architecture="TransformerDDPM")
+    table = {name: shape for name, _off, shape in model.engine.tensor_table}
+    want = FI.init_params(model.cfg, model_rng, table)
+    got = model.named_parameters()
+    for k in table:
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    other = N.create_model(N.PRNGKey(0), (32, 42), kw, architecture="TransformerDDPM")     # engine key: the old initialiser
+    assert not np.array_equal(other.named_parameters()["in_proj.kernel"].cpu().numpy(), want["in_proj.kernel"])
+
+
+def test_interpolate_matches_the_oracle_restatement():
+    """--interpolate (sample_ncsn.py:245-310,425-435): stochastic encode with the reference's key reuse (noise from ``rng``,
+    alphas_prod[T] clamped), 9-point lerp, every point decoded with the same ld_rng; 50-level schedule, jax.random streams."""
+    import ddpm_oracle as O
+    import sample_ncsn as S
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    T = 50
+    betas = O.create_noise_schedule(1e-6, 0.01, T, "linear")
+    ocfg = O.NetConfig(data_channels=42, num_layers=2, num_heads=8, num_mlp_layers=1)
+    p = O.init_params(ocfg, 0, torch.float64)
+    model = N.Model(NetConfig(data_channels=42, num_layers=2, num_heads=8, num_mlp_layers=1, num_timesteps=T), "cuda:0", seed=None)
+    model.engine.load_named(p)
+    g = torch.Generator().manual_seed(3)
+    real = torch.clamp(0.25 * torch.randn(3, 32, 42, generator=g), -1, 1).numpy()
+    seed = 7
+    with torch.no_grad():
+        gref, cref = O.interpolate_samples(O.make_model(p, ocfg), betas, real, seed)
+    root = N.make_key(seed, "threefry")
+    rng, _model_rng = N.split(root)                                              # load_model(): what main() passes as ``rng``
+    gen, coll, met = S.interpolate_samples(model, betas, real, 0, 3, rng, seed, "threefry", "cuda:0", use_graph=True)
+    assert gen.shape == (9, 3, 32, 42) and coll.shape == (9, 41, 3, 32, 42)
+    rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64)) / np.linalg.norm(np.asarray(b, np.float64)))
+    # the encoder alone is elementwise fp32: exact up to the normal's 1e-7
+    z = S.diffusion_stochastic_encoder(real, betas, rng, "cuda:0", 0, 3)
+    assert rel(z, O.diffusion_stochastic_encoder(real, betas, seed)) < 1e-6
+    assert rel(gen, gref.numpy()) < 2e-2, rel(gen, gref.numpy())
+    assert rel(coll[:, 0], cref[:, 0].numpy()) < 1e-6                             # slot 0 = the interpolated latent itself
+    assert rel(gen[0], gref[0].numpy()) < 2e-2 and rel(gen[8], gref[8].numpy()) < 2e-2
+    # both ends share the encoder noise: the end points' latents differ by sqrt(alpha_bar_T) (goals - starts) exactly
+    a_T = float(O.alphas_cumprod(betas)[-1])
+    assert rel(coll[8, 0] - coll[0, 0], np.sqrt(a_T) * (np.roll(real, 1, axis=0) - real)) < 1e-5
+    assert len(met) == T
