@@ -564,7 +564,7 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
     }
     LnArgs ln;
     ln.rows = R; ln.D = M; ln.film_scale = scale; ln.film_shift = scale + M; ln.ld_film = ld_film;
-    ln.rows_per_sample = S; ln.t_ptr = t_ptr; ln.swish = 1;
+    ln.rows_per_sample = S; ln.t_ptr = t_ptr; ln.film_rows = d_.num_timesteps; ln.swish = 1;
     if (f8) {
       // e4m3 forward GEMMs: the LayerNorm writes the A operand as e4m3 + row scales (and, when training, the bf16 copy
       // the weight gradient contracts), the weights were quantised per output row above

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(LnArgs a) {
 #pragma unroll
   for (int i = 0; i < L::PER_LANE; ++i) y[i] = (x[i] - mean) * rstd * g[i] + b[i];
   if (a.film_scale) {
-    const int frow = a.t_ptr ? smd_clamp_t(*a.t_ptr) : row / a.rows_per_sample;
+    const int frow = a.t_ptr ? smd_clamp_t(*a.t_ptr, a.film_rows) : row / a.rows_per_sample;
     float sc[L::PER_LANE], sh[L::PER_LANE];
     load_vec<D>(a.film_scale + (size_t)frow * a.ld_film, lane, sc);
     load_vec<D>(a.film_shift + (size_t)frow * a.ld_film, lane, sh);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, i
   int r_end = r_begin + group_rows;
   r_end = r_end < a.rows ? r_end : a.rows;
   {
-    const int frow = FS ? (a.t_ptr ? smd_clamp_t(*a.t_ptr) : r_begin / a.rows_per_sample) : 0;
+    const int frow = FS ? (a.t_ptr ? smd_clamp_t(*a.t_ptr, a.film_rows) : r_begin / a.rows_per_sample) : 0;
     const float* src[4] = {a.gamma, a.beta, FS ? a.film_scale + (size_t)frow * a.ld_film : nullptr,
                            FS ? a.film_shift + (size_t)frow * a.ld_film : nullptr};
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LnBwdDev a) {
   load_vec<D>(a.f.gamma, lane, g);
   load_vec<D>(a.f.beta, lane, b);
   if (film) {
-    const int frow = a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr) : r_begin / a.f.rows_per_sample;
+    const int frow = a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr, a.f.film_rows) : r_begin / a.f.rows_per_sample;
     load_vec<D>(a.f.film_scale + (size_t)frow * a.f.ld_film, lane, sc);
     load_vec<D>(a.f.film_shift + (size_t)frow * a.f.ld_film, lane, sh);
   }
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void layernorm_bwd_wide_kernel(LnBwdDev a) 
   const bool film = a.f.film_scale != nullptr;
   const bool swish = a.f.swish != 0;
   {
-    const int frow = film ? (a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr) : r_begin / a.f.rows_per_sample) : 0;
+    const int frow = film ? (a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr, a.f.film_rows) : r_begin / a.f.rows_per_sample) : 0;
     const float* src[4] = {a.f.gamma, a.f.beta, film ? a.f.film_scale + (size_t)frow * a.f.ld_film : nullptr,
                            film ? a.f.film_shift + (size_t)frow * a.f.ld_film : nullptr};
 #pragma unroll
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(512) void layernorm_bwd_wide8_kernel(LnBwdDev a) { 
   int r_end = r_begin + a.group_rows;
   r_end = r_end < a.f.rows ? r_end : a.f.rows;
   {
-    const int frow = film ? (a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr) : r_begin / a.f.rows_per_sample) : 0;
+    const int frow = film ? (a.f.t_ptr ? smd_clamp_t(*a.f.t_ptr, a.f.film_rows) : r_begin / a.f.rows_per_sample) : 0;
     const float* src[4] = {a.f.gamma, a.f.beta, film ? a.f.film_scale + (size_t)frow * a.f.ld_film : nullptr,
                            film ? a.f.film_shift + (size_t)frow * a.f.ld_film : nullptr};
 #pragma unroll
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
 }
 
 // dgamma / dbeta of several LayerNorms in one launch: entry e sums partial_e[g][0|1][c] over its groups in a fixed
-// order (4 group slices per block, combined through LDS) and ACCUMULATES into the gradient buffer.
+// order (4 group slices per block, combined through LDS) and WRITES the gradient (no memset needed, no accumulation).
 __global__ __launch_bounds__(256) void ln_bwd_reduce_batched_kernel(LnReduceTable t) {
   __shared__ float red[4][64];
   int e = 0;

@@ -101,6 +101,7 @@ struct LnArgs {
   int ld_film = 0;
   int rows_per_sample = 1;
   const int* t_ptr = nullptr;
+  int film_rows = 1 << 30;           // rows of the FiLM table when t_ptr indexes it (num_timesteps): *t_ptr is clamped to it
   int swish = 0;
   bf16_t* out = nullptr;             // [rows][D]
   // e4m3 copy of the output with one power-of-two scale per row (D = 1024 / 2048 row-group kernels only): out_f8

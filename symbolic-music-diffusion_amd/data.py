@@ -114,6 +114,10 @@ class ArrayLatents:
         perm = torch.randperm(len(self.array), generator=g)
         return perm[self.rank * self.per_rank:(self.rank + 1) * self.per_rank]
 
+    def set_epoch(self, epoch: int) -> None:
+        """The training loop's epoch (a resumed run continues with the permutation of ITS epoch, not epoch 0's)."""
+        self.epoch = int(epoch)
+
     def __iter__(self) -> Iterator[torch.Tensor]:
         if not self.shuffle:
             for i in range(self.examples):

@@ -52,7 +52,7 @@ def test_quantize_rows_e4m3(L, dev):
     ck(L, L.smd_quantize_rows_e4m3(P(xd), K, rows, K, P(q), P(s), st()))
     torch.cuda.synchronize()
     amax = x.float().abs().amax(1)
-    e_ref = torch.where(amax > 0, torch.floor(torch.log2(amax.double())).to(torch.int64) - 8, torch.zeros(rows, dtype=torch.int64))
+    e_ref = torch.where(amax > 0, torch.ceil(torch.log2(amax.double() / 448.0)).to(torch.int64), torch.zeros(rows, dtype=torch.int64))
     assert torch.equal((s.cpu().to(torch.int64) & 0xFF) - 127, e_ref)
     want = (x.float() * torch.pow(2.0, -e_ref.float()).unsqueeze(1)).clamp(-448, 448).to(torch.float8_e4m3fn)
     same = (want.view(torch.uint8) == q.cpu()).float().mean()
@@ -112,7 +112,7 @@ def test_layernorm_fwd_e4m3(L, dev):
     d = dequant(q, s)
     print(f"layernorm_fwd_e4m3: e4m3 rel {rel(d, y):.2e}, bf16 copy rel {rel(ob.float(), y):.2e}")
     assert rel(d, y) < 4e-2 and rel(ob.float(), y) < 4e-3
-    e_ref = torch.floor(torch.log2(y.abs().amax(1))).to(torch.int64) - 8
+    e_ref = torch.ceil(torch.log2(y.abs().amax(1).double() / 448.0)).to(torch.int64)
     assert ((((s.cpu().to(torch.int64) & 0xFF) - 127) - e_ref).abs() <= 1).all()      # bf16-free fp32 row maximum: same binade
 
 

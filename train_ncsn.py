@@ -78,6 +78,10 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
     model = ncsn.create_model(model_rng, input_shape, model_kwargs, FLAGS.batch_size, verbose=verbose and rank == 0,
                               architecture=FLAGS.architecture, num_timesteps=len(sigmas), device=dev, dtype=FLAGS.dtype)
     optimizer = create_optimizer(model, FLAGS.learning_rate, ema=FLAGS.ema)       # :332
+    optimizer.engine.set_option("trunk_bf16", 2 if FLAGS.trunk_dtype == "bf16" else 1)
+    optimizer.engine.trunk_dtype = FLAGS.trunk_dtype                               # recorded in the checkpoint metadata
+    if rank == 0:
+        log.info("training trunk dtype: %s (GEMM operands: %s)", FLAGS.trunk_dtype, FLAGS.dtype)
     comm = GradComm() if world > 1 else None
     if comm is not None:
         comm.broadcast_params(model.params)
@@ -93,6 +97,8 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
     sampling_step = -1
     for epoch in range(FLAGS.epochs):
         start_time = time.time()
+        if hasattr(train_batches, "set_epoch"):
+            train_batches.set_epoch(epoch)          # the shuffle of epoch e is a function of (seed, e), also after a resume
         for step, batch in enumerate(train_batches):
             rng, train_rng = ncsn.split(rng)                                      # :358
             global_step = step + epoch * train_batches.examples                   # :359
