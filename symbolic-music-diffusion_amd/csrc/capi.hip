@@ -96,6 +96,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "label_min") { e->impl.label_min = value ? 1 : 0; return 0; }
   if (std::string(key) == "mlp_hs") { e->impl.mlp_hs = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
+  if (std::string(key) == "fp8_dgrad") { e->impl.fp8_dgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "w8_dirty") { e->impl.mark_w8_dirty(); return 0; }   // the bf16 operand pack changed under another handle
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;

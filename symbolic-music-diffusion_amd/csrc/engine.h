@@ -149,6 +149,10 @@ class SmdEngine {
   // e4m3 (OCP fp8) operands with per-row E8M0 scales for the DenseResBlock GEMMs of the FORWARD pass (77 % of its flops),
   // v_mfma_scale_f32_32x32x64_f8f6f4; everything else, and the whole backward pass, stays bf16.  Set before bind_workspace.
   int fp8 = 0;
+  // fp8 mode, training: the four DenseResBlock DGRAD GEMMs (dX = dY W^T, 8192 x 2048 x 2048 each) also run on e4m3
+  // operands -- dY quantised per row (one E8M0 scale per token row) right before the GEMM, the dgrad layout of the weights
+  // quantised per row next to the forward layout; the weight gradients and everything 128-wide stay bf16.
+  int fp8_dgrad = 1;
   int mlp_hs = 1;              // hidden-split fused MLP half-layers (forward; backward with recompute); 0: the older paths
 
  private:
@@ -223,6 +227,10 @@ class SmdEngine {
     std::vector<uint32_t*> sa1, sa2;
     unsigned char* w8 = nullptr;          // [K blocks][r1, r2][M][M] e4m3 weights (rows = output features)
     uint32_t* w8s = nullptr;              // [K blocks][r1, r2][M] row scales
+    unsigned char* w8d = nullptr;         // the same for the dgrad layout (rows = input features), training only
+    uint32_t* w8ds = nullptr;
+    unsigned char* dy8 = nullptr;         // [R][M] e4m3 copy of the gradient entering a dgrad GEMM + its row scales
+    uint32_t* sdy = nullptr;
     bf16_t* ao = nullptr;
     bf16_t* emb = nullptr;                // [B][F]
     std::vector<bf16_t*> zf1, f1, p;      // [B][4F]

@@ -284,6 +284,12 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     }
     t.w8 = c.take<unsigned char>((size_t)K * 2 * M * M);
     t.w8s = c.take<uint32_t>((size_t)K * 2 * M);
+    if (training) {
+      t.w8d = c.take<unsigned char>((size_t)K * 2 * M * M);
+      t.w8ds = c.take<uint32_t>((size_t)K * 2 * M);
+      t.dy8 = c.take<unsigned char>(R * M);
+      t.sdy = c.take<uint32_t>(R);
+    }
   }
   t.ao = training ? c.take<bf16_t>(R * M) : t.ya1[0];
   t.emb = c.take<bf16_t>(B * F);
@@ -540,6 +546,11 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       RC(launch_quantize_rows_e4m3(wpack_ + b.r1.Wt_off, b.r1.Kp, M, M, W.w8 + (size_t)k * 2 * M * M, W.w8s + (size_t)k * 2 * M, st));
       RC(launch_quantize_rows_e4m3(wpack_ + b.r2.Wt_off, b.r2.Kp, M, M, W.w8 + (size_t)k * 2 * M * M + (size_t)M * M,
                                    W.w8s + (size_t)k * 2 * M + M, st));
+      if (tr && fp8_dgrad && W.w8d) {      // dgrad layout W[in][out]: one scale per input feature row
+        RC(launch_quantize_rows_e4m3(wpack_ + b.r1.W_off, b.r1.Np, M, M, W.w8d + (size_t)k * 2 * M * M, W.w8ds + (size_t)k * 2 * M, st));
+        RC(launch_quantize_rows_e4m3(wpack_ + b.r2.W_off, b.r2.Np, M, M, W.w8d + (size_t)k * 2 * M * M + (size_t)M * M,
+                                     W.w8ds + (size_t)k * 2 * M + M, st));
+      }
     }
     w8_dirty_ = false;
   }
@@ -672,10 +683,21 @@ int SmdEngine::backward_head(hipStream_t st) {
     b.dgamma = G(ln_o_.g_off); b.dbeta = G(ln_o_.b_off);
     RC(ln_bwd(b, st));
   }
+  // fp8 mode: dX = dY W^T of the two 2048 x 2048 layers of a block on e4m3 operands (quantise dY per token row, then the
+  // scaled-MFMA GEMM against the e4m3 copy of the dgrad pack); the weight gradient is issued first, as in dense_bwd
+  const bool f8d = fp8 && fp8_dgrad && W.w8d && W.dy8 && R % 256 == 0 && M % 256 == 0 && (M == 1024 || M == 2048) && !w8_dirty_;
+  auto res_bwd = [&](const DenseP& p, int widx, const bf16_t* X, const bf16_t* dY) -> int {
+    if (!f8d) return dense_bwd(p, X, M, dY, M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true);
+    RC(wgrad(p, X, M, dY, M, R, true, st));
+    RC(launch_quantize_rows_e4m3(dY, M, R, M, W.dy8, W.sdy, st));
+    GemmEpilogue ep;
+    ep.out_bf16 = W.dA_M; ep.ld_outb = M;
+    return launch_gemm_nt256_fp8(W.dy8, M, W.sdy, W.w8d + (size_t)widx * M * M, M, W.w8ds + (size_t)widx * M, R, M, M, ep, st);
+  };
   for (int k = K - 1; k >= 0; --k) {
     const FilmResP& p = blk_[k];
     // fc2 of the res block: y[k+1] = ya2 W + b + y[k]
-    RC(dense_bwd(p.r2, W.ya2[k], M, W.dyb[k + 1], M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
+    RC(res_bwd(p.r2, 2 * k + 1, W.ya2[k], W.dyb[k + 1]));
     {
       LnBwdArgs b;
       b.f = ln_args(nullptr, W.o1[k], R, p.ln2, params_);
@@ -686,7 +708,7 @@ int SmdEngine::backward_head(hipStream_t st) {
       b.dscale = W.dss[k]; b.dshift = W.dss[k] + M; b.dfilm_accumulate = 0;
       RC(ln_bwd(b, st));
     }
-    RC(dense_bwd(p.r1, W.ya1[k], M, W.do1[k], M, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
+    RC(res_bwd(p.r1, 2 * k, W.ya1[k], W.do1[k]));
     {
       LnBwdArgs b;
       b.f = trunk_bf16_on() ? ln_args(nullptr, reinterpret_cast<bf16_t*>(W.y[k]), R, p.ln1, params_)
