@@ -85,6 +85,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "resgrad_bf16") { e->impl.resgrad_bf16 = value ? 1 : 0; return 0; }
   if (std::string(key) == "film_side") { e->impl.film_side = value; return 0; }
   if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
+  if (std::string(key) == "wgrad256_group") { e->impl.wgrad256_group = value < 1 ? 1 : (value > 4 ? 4 : value); return 0; }
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   if (std::string(key) == "trunk_bf16") { e->impl.trunk_bf16 = value; return 0; }

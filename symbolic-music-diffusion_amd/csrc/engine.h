@@ -138,7 +138,9 @@ class SmdEngine {
   int tail_on_main = 1;    // the last grouped wgrad launch of a step runs on the caller's stream (which would idle) while
                            // the side stream drains its backlog
   int film_side_fwd = 1;   // training: FiLM generators (forward) and their backward chain run on the side stream
-  int pair_wgrad = 1;                                         // the two 2048x2048 wgrads of a DenseResBlock in one launch
+  int pair_wgrad = 1;                                         // the 2048x2048 wgrads of the DenseResBlocks in grouped launches
+  int wgrad256_group = 4;  // problems per 256x256-kernel wgrad launch: 4 (default: 256 tiles, no split over m, no slab reduce),
+                           // 2 = one launch per DenseResBlock with two m-splits (round 2)
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
                                                               // layer as soon as its backward is enqueued (+4.6 % train), 1 = all at
                                                               // the end of the backward (+3 %), 0 = one launch + reduce each
@@ -171,8 +173,8 @@ class SmdEngine {
   int flush_ln_reduce(hipStream_t st);
   int flush_grouped_wgrads(hipStream_t st, bool on_caller_stream = false);
   std::vector<TnLaunch> deferred_wgrads_;
-  TnLaunch pending256_;
-  bool have_pending256_ = false;
+  std::vector<TnLaunch> pending256_;          // 256x256-kernel wgrad problems waiting for their group (wgrad256_group)
+  int flush_pending256(hipStream_t st);
   std::vector<LnReduceEntry> ln_pending_;
   size_t ln_slot_off_ = 0;
   float* P(int64_t off) const { return params_ + off; }

@@ -78,18 +78,12 @@ int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY
   }
   if (!(allow_side && side_wgrad && side_ && tr_path)) return launch_gemm_tn(t, st);
   t.slab = W.tn_slab_side;
-  if (pair_wgrad) {                      // a 256x256-kernel problem: wait for its partner (fc2 then fc1 of one DenseResBlock)
+  if (pair_wgrad) {                      // a 256x256-kernel problem: wait for its partners (the Dense layers of the DenseResBlocks)
     int per = 0;
     if (gemm_tn256_plan(t, &per) > 0) {
-      if (!have_pending256_) { pending256_ = t; have_pending256_ = true; return 0; }
-      have_pending256_ = false;
-      hipEvent_t ev2 = take_event();
-      SMD_ARG_CHECK(ev2, "wgrad: cannot create an event");
-      hipError_t e2 = hipEventRecord(ev2, st);
-      if (e2 == hipSuccess) e2 = hipStreamWaitEvent(side_, ev2, 0);
-      if (e2 != hipSuccess) { smd_set_error("wgrad: event: %s", hipGetErrorString(e2)); return (int)e2; }
-      side_pending_ = true;
-      return launch_gemm_tn256_pair(pending256_, t, side_);
+      pending256_.push_back(t);
+      if ((int)pending256_.size() < wgrad256_group) return 0;
+      return flush_pending256(st);
     }
   }
   hipEvent_t ev = take_event();
@@ -99,6 +93,25 @@ int SmdEngine::wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY
   if (e != hipSuccess) { smd_set_error("wgrad: event: %s", hipGetErrorString(e)); return (int)e; }
   side_pending_ = true;
   return launch_gemm_tn(t, side_);
+}
+
+// The collected 256x256-kernel weight gradients as ONE side-stream launch behind everything the main stream has enqueued so
+// far (four 2048 x 2048 problems = 256 tiles: no split over m, no slabs, no reduce; fewer: two or four m-splits)
+int SmdEngine::flush_pending256(hipStream_t st) {
+  if (pending256_.empty()) return 0;
+  hipEvent_t ev = take_event();
+  SMD_ARG_CHECK(ev, "wgrad: cannot create an event");
+  hipError_t e2 = hipEventRecord(ev, st);
+  if (e2 == hipSuccess) e2 = hipStreamWaitEvent(side_, ev, 0);
+  if (e2 != hipSuccess) { smd_set_error("wgrad: event: %s", hipGetErrorString(e2)); return (int)e2; }
+  side_pending_ = true;
+  int rc = 0;
+  for (size_t i = 0; i < pending256_.size() && rc == 0; i += SMD_TN256_MULTI_MAX) {
+    const int n = (int)std::min<size_t>(SMD_TN256_MULTI_MAX, pending256_.size() - i);
+    rc = launch_gemm_tn256_multi(pending256_.data() + i, n, side_);
+  }
+  pending256_.clear();
+  return rc;
 }
 
 // The deferred 128-wide weight gradients (every operand is a saved activation or a per-use gradient slot, so
@@ -133,16 +146,7 @@ int SmdEngine::flush_grouped_wgrads(hipStream_t st, bool on_caller_stream) {
 }
 
 int SmdEngine::join_side(hipStream_t st) {
-  if (have_pending256_) {                // an unpaired 256x256 problem
-    have_pending256_ = false;
-    hipEvent_t ev0 = take_event();
-    SMD_ARG_CHECK(ev0, "join_side: cannot create an event");
-    hipError_t e0 = hipEventRecord(ev0, st);
-    if (e0 == hipSuccess) e0 = hipStreamWaitEvent(side_, ev0, 0);
-    if (e0 != hipSuccess) { smd_set_error("join_side: %s", hipGetErrorString(e0)); return (int)e0; }
-    side_pending_ = true;
-    RC(launch_gemm_tn(pending256_, side_));
-  }
+  if (!pending256_.empty()) RC(flush_pending256(st));      // an incomplete group of 256x256 problems
   if (!side_pending_) { next_event_ = 0; return 0; }
   hipEvent_t ev = take_event();
   SMD_ARG_CHECK(ev, "join_side: cannot create an event");

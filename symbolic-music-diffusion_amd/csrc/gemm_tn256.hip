@@ -97,9 +97,13 @@ struct Tn256Args {
   int tiles_n, tiles_k, ktiles_per_split, nwg;
 };
 
-// Up to two problems per launch (the two Dense layers of one DenseResBlock): with 2 x 64 tiles two m-splits fill
-// the chip, which halves the slab traffic of a lone problem's four splits.
-struct Tn256Group { int ngroups; int nwg_total; Tn256Args p[2]; };
+// Up to four problems per launch.  Four 2048 x 2048 weight gradients (the Dense layers of two DenseResBlocks) are 4 x 64 =
+// 256 tiles: one per CU with NO split over m -- every block walks the whole contraction (128 K-tiles instead of 32: the
+// fixed cost of a block is paid once), writes its tile straight into the gradient buffer, and the slab round trip and the
+// reduce launches of the split form disappear (round 3: 4 x 69.6 us + 4 x 22.1 us -> one launch).  Two problems: two
+// m-splits fill the chip (half the slab traffic of a lone problem's four splits).
+#define SMD_TN256_GROUP_MAX 4
+struct Tn256Group { int ngroups; int nwg_total; Tn256Args p[SMD_TN256_GROUP_MAX]; };
 
 __global__ __launch_bounds__(512) void gemm_tn256_kernel(Tn256Group ga) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM_BYTES];
@@ -108,8 +112,8 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(Tn256Group ga) {
   const int bid = blockIdx.x;
   const int q = ga.nwg_total >> 3, r = ga.nwg_total & 7, xcd = bid & 7;
   int vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int gsel = (ga.ngroups > 1 && vid >= ga.p[0].nwg) ? 1 : 0;
-  if (gsel) vid -= ga.p[0].nwg;
+  int gsel = 0;
+  while (gsel + 1 < ga.ngroups && vid >= ga.p[gsel].nwg) { vid -= ga.p[gsel].nwg; ++gsel; }
   const Tn256Args a = ga.p[gsel];
   const int tiles = a.tiles_k * a.tiles_n;
   const int split = vid / tiles, tile = vid - split * tiles;
@@ -397,31 +401,60 @@ int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipSt
   return reduce_tn256(t, ga.p[0], nsplit, st);
 }
 
-// Two tn256-eligible problems of the same shape class in one launch (slabs carved from t0.slab).
-int launch_gemm_tn256_pair(const TnLaunch& t0, const TnLaunch& t1, hipStream_t st) {
-  int per0 = 0, per1 = 0;
-  const int n0 = gemm_tn256_plan(t0, &per0), n1 = gemm_tn256_plan(t1, &per1);
-  SMD_ARG_CHECK(n0 > 0 && n1 > 0, "gemm_tn256_pair: problem not eligible for the 256x256 kernel");
-  const int tiles0 = (t0.Kd / TM) * (t0.N / TN), tiles1 = (t1.Kd / TM) * (t1.N / TN);
-  const int total_kt = (t0.Mrows + TKM - 1) / TKM;
-  SMD_ARG_CHECK(t0.Mrows == t1.Mrows, "gemm_tn256_pair: different contraction lengths");
-  int nsplit = (256 + tiles0 + tiles1 - 1) / (tiles0 + tiles1);
+// n <= 4 tn256-eligible problems with the same contraction length in one launch.  The split over m is chosen for the whole
+// group (one workgroup per CU): 4 x 64 tiles -> no split, 2 x 64 -> two, 1 x 64 -> four.  Without a split the tiles are
+// written straight to the gradient (ldo) and only the bias partial rows (tiles_k per problem) go through the reduce kernel.
+int launch_gemm_tn256_multi(const TnLaunch* ts, int n, hipStream_t st) {
+  SMD_ARG_CHECK(ts && n >= 1 && n <= SMD_TN256_GROUP_MAX, "gemm_tn256_multi: 1..%d problems", SMD_TN256_GROUP_MAX);
+  const int total_kt = (ts[0].Mrows + TKM - 1) / TKM;
+  int tiles_all = 0;
+  for (int i = 0; i < n; ++i) {
+    int per_i = 0;
+    SMD_ARG_CHECK(gemm_tn256_plan(ts[i], &per_i) > 0, "gemm_tn256_multi: problem %d not eligible for the 256x256 kernel", i);
+    SMD_ARG_CHECK(ts[i].Mrows == ts[0].Mrows, "gemm_tn256_multi: different contraction lengths");
+    tiles_all += (ts[i].Kd / TM) * (ts[i].N / TN);
+  }
+  int nsplit = 256 / tiles_all;
   if (nsplit * 4 > total_kt) nsplit = total_kt / 4;
   if (nsplit < 1) nsplit = 1;
   int per = (total_kt + nsplit - 1) / nsplit;
   per = (per + 1) & ~1;
   nsplit = (total_kt + per - 1) / per;
-  const size_t need0 = (size_t)nsplit * t0.Kd * t0.N + (size_t)nsplit * (t0.Kd / TM) * t0.N;
-  const size_t need1 = (size_t)nsplit * t1.Kd * t1.N + (size_t)nsplit * (t1.Kd / TM) * t1.N;
-  SMD_ARG_CHECK(need0 + need1 <= t0.slab_elems, "gemm_tn256_pair: slab workspace too small");
   Tn256Group ga;
-  ga.ngroups = 2;
-  fill_tn256(ga.p[0], t0, nsplit, per, t0.slab);
-  fill_tn256(ga.p[1], t1, nsplit, per, t0.slab + ((need0 + 3) / 4 * 4));
-  ga.nwg_total = ga.p[0].nwg + ga.p[1].nwg;
+  ga.ngroups = n;
+  ga.nwg_total = 0;
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const TnLaunch& t = ts[i];
+    const size_t n_w = (size_t)t.Kd * t.N, bias_rows = (size_t)nsplit * (t.Kd / TM) * t.N;
+    const size_t need = (nsplit > 1 ? (size_t)nsplit * n_w : 0) + bias_rows;
+    SMD_ARG_CHECK(off + need <= ts[0].slab_elems, "gemm_tn256_multi: slab workspace too small");
+    fill_tn256(ga.p[i], t, nsplit, per, ts[0].slab + off);
+    if (nsplit == 1) {                    // tiles go straight to the gradient; the slab only holds the bias partial rows
+      SMD_ARG_CHECK(t.ldo % 4 == 0, "gemm_tn256_multi: ldo must be a multiple of 4");
+      ga.p[i].dst = t.out; ga.p[i].ld = t.ldo; ga.p[i].split_stride = 0;
+      ga.p[i].bias_dst = t.bias_out ? ts[0].slab + off : nullptr;
+    }
+    ga.nwg_total += ga.p[i].nwg;
+    off += (need + 3) / 4 * 4;
+  }
   hipLaunchKernelGGL(gemm_tn256_kernel, dim3(ga.nwg_total), dim3(512), smd_tn_pad_bytes(SMEM_BYTES), st, ga);
   SMD_LAUNCH_CHECK();
-  int rc = reduce_tn256(t0, ga.p[0], nsplit, st);
-  if (rc) return rc;
-  return reduce_tn256(t1, ga.p[1], nsplit, st);
+  for (int i = 0; i < n; ++i) {
+    const TnLaunch& t = ts[i];
+    if (nsplit > 1) {
+      const int rc = reduce_tn256(t, ga.p[i], nsplit, st);
+      if (rc) return rc;
+    } else if (t.bias_out) {              // column sums: tiles_k partial rows -> db
+      hipLaunchKernelGGL(reduce_slabs256_kernel, dim3((unsigned)((t.N / 4 + 255) / 256)), dim3(256), 0, st, ga.p[i].bias_dst, (size_t)0, 1,
+                         (size_t)0, t.out, t.ldo, t.N, ga.p[i].bias_dst, ga.p[i].tiles_k, t.bias_out);
+      SMD_LAUNCH_CHECK();
+    }
+  }
+  return 0;
+}
+
+int launch_gemm_tn256_pair(const TnLaunch& t0, const TnLaunch& t1, hipStream_t st) {
+  const TnLaunch ts[2] = {t0, t1};
+  return launch_gemm_tn256_multi(ts, 2, st);
 }

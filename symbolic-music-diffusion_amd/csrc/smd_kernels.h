@@ -77,6 +77,8 @@ int smd_tn_pad_bytes(int static_lds_bytes);
 int gemm_tn256_plan(const TnLaunch& t, int* ktiles_per_split);
 int launch_gemm_tn256(const TnLaunch& t, int nsplit, int ktiles_per_split, hipStream_t st);
 int launch_gemm_tn256_pair(const TnLaunch& t0, const TnLaunch& t1, hipStream_t st);   // two problems, one launch
+#define SMD_TN256_MULTI_MAX 4
+int launch_gemm_tn256_multi(const TnLaunch* ts, int n, hipStream_t st);                 // 1..4 problems, one launch (4 x 64 tiles: no split-K)
 int launch_gemm_tn(const TnLaunch& t, hipStream_t st);
 // n wgrad problems with the same Mrows (ldo == N each) in grouped launches of the 128-wide kernel + one reduce
 int launch_gemm_tn_grouped(const TnLaunch* probs, int n, hipStream_t st);
