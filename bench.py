@@ -234,12 +234,10 @@ class Workload:
 
     def _reset_t(self):
         torch = self.torch
-        for ch in self.chains:
-            if ch["stream"] is not None:
-                with torch.cuda.stream(ch["stream"]):
-                    ch["t_ptr"].fill_(999)
-            else:
-                ch["t_ptr"].fill_(999)
+        import smd_amd.lib as lib
+        for ch in self.chains:       # the engine's own one-thread kernel on the chain's stream (no framework fill on the replay stream)
+            st = ch["stream"] if ch["stream"] is not None else torch.cuda.current_stream()
+            lib.check(lib.get_lib().smd_set_timestep(ch["t_ptr"].data_ptr(), 999, st.cuda_stream))
         self.walked = 0
 
     def one_sample(self):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 2   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries */
+#define SMD_ABI_VERSION 3   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots */
 
 typedef uint16_t smd_bf16;
 typedef struct smd_engine smd_engine;
@@ -93,6 +93,12 @@ int smd_engine_refresh_weights(smd_engine* e, void* stream);   /* fp32 master ->
 
 /* nn.Model.__call__: model(x:(B,S,C), noise_level:(B,)) -> eps_hat (models/ncsn.py:141-179, 125-135) */
 int smd_engine_forward(smd_engine* e, const float* x, const float* noise_level, float* eps_out, void* stream);
+/* model(x, level) for a BATCH-UNIFORM noise level given as a device-side row index into the FiLM tables built by
+ * smd_engine_prepare_sampler (row r = noise level sqrt_ap[r] of the bound schedule): no FiLM-generator launches and nothing
+ * step-dependent on the host, so an (eps-net forward + Langevin update) pair can be captured once and replayed
+ * (utils/ebm_utils.py:140,242 -- the noise level is the same for the whole batch inside both Langevin samplers).  out may be
+ * NULL: the result then stays in the engine's own buffer, smd_engine_pred(). */
+int smd_engine_forward_level(smd_engine* e, const float* x, const int32_t* level_ptr, float* out, void* stream);
 
 /* diffusion_loss + value_and_grad (utils/losses.py:250-308, train_ncsn.py:282-283).
  * labels/eps_in NULL -> on-device Philox draws keyed by (seed, global sample index, step).
@@ -170,8 +176,27 @@ typedef struct smd_langevin_io {
   float infill_sigma;
   float* metrics_partial;
   float* collect_out;
+  /* Table mode (graph-captured loops; ABI version 3): with k_ptr != NULL the update takes its step-dependent arguments from
+   * device memory, indexed by the device-side update counter k = *k_ptr, so that ONE captured (forward + update) pair can be
+   * replayed for a whole annealed / consistent run:  alpha, noise_coef, infill_sigma = step_table[k][0..2]; the Philox counter
+   * word and (use_threefry) the two keys key_table[k][0..1 | 2..3] are those of update k; metrics_partial is the base of an
+   * [n_steps][B][3] array (row k is written); the new state is copied to collection + slot_table[k] * B*S*C when that slot
+   * is >= 0; sigma_out[b] receives step_table[k][3], the noise level of the NEXT forward pass (level_out its table row); the launch's last workgroup
+   * stores k + 1 to k_ptr (arrive: one zeroed uint32).  k outside [0, n_steps) makes the launch a no-op. */
+  const float* step_table;
+  const int32_t* slot_table;
+  const uint32_t* key_table;
+  int32_t* k_ptr;
+  uint32_t* arrive;
+  float* collection;
+  float* sigma_out;
+  int32_t n_steps;
+  int32_t* level_out;        /* one int32: receives min((k + 1) / steps_per_level, n_levels - 1), the FiLM-table row of the next forward */
+  int32_t steps_per_level, n_levels;
 } smd_langevin_io;
 int smd_langevin_step(const smd_langevin_io* io, int B, int S, int C, void* stream);
+/* *t_ptr = t on `stream`: restarts a reverse walk (the device-side timestep of smd_engine_sample_step) without a framework fill */
+int smd_set_timestep(int32_t* t_ptr, int32_t t, void* stream);
 
 /* process-wide kernel-selection knob for benchmark A/B runs (defaults = fast paths).
  * "gemm_nt256": 1 = large Dense GEMMs use the 256x256 8-phase kernel (default), 0 = 128-wide tiles only,

@@ -121,6 +121,10 @@ int smd_engine_forward(smd_engine* e, const float* x, const float* s, float* out
   NEED(e);
   return e->impl.forward(x, s, out, S(stream));
 }
+int smd_engine_forward_level(smd_engine* e, const float* x, const int32_t* level_ptr, float* out, void* stream) {
+  NEED(e);
+  return e->impl.forward_level(x, level_ptr, out, S(stream));
+}
 int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labels, const float* eps_in,
                              uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset, float inv_global_count,
                              int stage, void* stream) {
@@ -328,6 +332,7 @@ int smd_adam_clip_ema(float* params, const float* grads, float* m, float* v, flo
   int rc = launch_grad_sumsq(a, S(stream));
   return rc ? rc : launch_adam_clip_ema(a, S(stream));
 }
+int smd_set_timestep(int32_t* t_ptr, int32_t t, void* stream) { return launch_set_t(t_ptr, t, S(stream)); }
 int smd_langevin_step(const smd_langevin_io* io, int Bn, int Sn, int C, void* stream) {
   SMD_ARG_CHECK(io, "langevin_step: null io");
   LangevinStepArgs a;
@@ -339,6 +344,9 @@ int smd_langevin_step(const smd_langevin_io* io, int Bn, int Sn, int C, void* st
   a.tf_n_total = io->tf_n_total;
   a.infill_samples = io->infill_samples; a.infill_masks = io->infill_masks; a.infill_z_in = io->infill_z_in;
   a.infill_sigma = io->infill_sigma; a.metrics_partial = io->metrics_partial; a.collect_out = io->collect_out;
+  a.step_table = io->step_table; a.slot_table = io->slot_table; a.key_table = io->key_table; a.k_ptr = io->k_ptr;
+  a.arrive = io->arrive; a.collection = io->collection; a.sigma_out = io->sigma_out; a.n_steps = io->n_steps;
+  a.level_out = io->level_out; a.steps_per_level = io->steps_per_level; a.n_levels = io->n_levels;
   return launch_langevin_step(a, S(stream));
 }
 int smd_rng_normal(float* out, int Bn, int per_sample, uint32_t lo, uint32_t hi, uint32_t stream_id, uint32_t off, void* stream) {

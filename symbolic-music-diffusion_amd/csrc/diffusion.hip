@@ -334,6 +334,7 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
 }
 
 __global__ void advance_t_kernel(int* t_ptr) { *t_ptr -= 1; }
+__global__ void set_t_kernel(int* t_ptr, int v) { *t_ptr = v; }
 
 // ------------------------------------------------------------------ Langevin update (annealed / consistent)
 // utils/ebm_utils.py:131-164 (langevin_step of annealed_langevin_dynamics) and :231-253 (consistent):
@@ -346,7 +347,27 @@ __global__ __launch_bounds__(256) void langevin_step_kernel(LangevinStepArgs a) 
   const uint32_t bglob = (uint32_t)b + a.sample_offset;
   const size_t sample_base = (size_t)b * a.S * a.C;
   const uint64_t tf_base = (uint64_t)bglob * a.S * a.C;
-  const TfKey nk{a.tf_noise_key[0], a.tf_noise_key[1]}, ik{a.tf_infill_key[0], a.tf_infill_key[1]};
+  TfKey nk{a.tf_noise_key[0], a.tf_noise_key[1]}, ik{a.tf_infill_key[0], a.tf_infill_key[1]};
+  int kstep = 0;
+  if (a.k_ptr) {          // table mode: this update's arguments from device memory (one captured launch serves every update)
+    kstep = *a.k_ptr;
+    if (kstep < 0 || kstep >= a.n_steps) return;
+    const float4 row = *reinterpret_cast<const float4*>(a.step_table + (size_t)kstep * 4);
+    a.alpha = row.x; a.noise_coef = row.y; a.infill_sigma = row.z;
+    a.step = (uint32_t)kstep;
+    if (a.key_table) {
+      const uint4 kk = *reinterpret_cast<const uint4*>(a.key_table + (size_t)kstep * 4);
+      nk = TfKey{kk.x, kk.y}; ik = TfKey{kk.z, kk.w};
+    }
+    const int slot = a.slot_table ? a.slot_table[kstep] : -1;
+    a.collect_out = (slot >= 0 && a.collection) ? a.collection + (size_t)slot * a.B * a.S * a.C : nullptr;
+    if (a.metrics_partial) a.metrics_partial += (size_t)kstep * a.B * 3;
+    if (a.sigma_out && threadIdx.x == 0) a.sigma_out[b] = row.w;
+    if (a.level_out && b == 0 && threadIdx.x == 0) {
+      const int lv = (kstep + 1) / (a.steps_per_level > 0 ? a.steps_per_level : 1);
+      *a.level_out = lv < a.n_levels ? lv : a.n_levels - 1;
+    }
+  }
   float m_g = 0.f, m_s = 0.f, m_z = 0.f;
   for (int c = threadIdx.x; c < a.C; c += 256) {
     float acc_g = 0.f, acc_s = 0.f, acc_z = 0.f;
@@ -386,6 +407,14 @@ __global__ __launch_bounds__(256) void langevin_step_kernel(LangevinStepArgs a) 
       float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
       if (a.S == 1) v = sqrtf(v + 1e-10f);
       a.metrics_partial[(size_t)b * 3 + threadIdx.x] = v;
+    }
+  }
+  // table mode: *k_ptr = k + 1 by the LAST workgroup to get here (every workgroup read k at its top, before its own arrival)
+  if (a.k_ptr && a.arrive && threadIdx.x == 0) {
+    const unsigned prev = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __hip_atomic_exchange(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.k_ptr, kstep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -485,6 +514,7 @@ int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st) {
 int launch_langevin_step(const LangevinStepArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.x && a.grad && a.B > 0 && a.S > 0 && a.C > 0, "langevin_step: bad arguments");
   SMD_ARG_CHECK(!a.infill_masks || a.infill_samples, "langevin_step: infill needs both the samples and the masks");
+  SMD_ARG_CHECK(!a.k_ptr || (a.step_table && a.arrive && a.n_steps > 0), "langevin_step: table mode needs step_table, arrive and n_steps");
   SMD_ARG_CHECK(!a.use_threefry || (a.tf_n_total >= ((int64_t)a.sample_offset + a.B) * a.S * a.C && a.tf_n_total <= (1ll << 32)),
                 "langevin_step: tf_n_total=%lld must cover this rank's window and be <= 2^32", (long long)a.tf_n_total);
   hipLaunchKernelGGL(langevin_step_kernel, dim3(a.B), dim3(256), 0, st, a);
@@ -492,6 +522,12 @@ int launch_langevin_step(const LangevinStepArgs& a, hipStream_t st) {
   return 0;
 }
 
+int launch_set_t(int* t_ptr, int v, hipStream_t st) {
+  SMD_ARG_CHECK(t_ptr, "set_t: null pointer");
+  hipLaunchKernelGGL(set_t_kernel, dim3(1), dim3(1), 0, st, t_ptr, v);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
 int launch_advance_t(int* t_ptr, hipStream_t st) {
   SMD_ARG_CHECK(t_ptr, "advance_t: null pointer");
   hipLaunchKernelGGL(advance_t_kernel, dim3(1), dim3(1), 0, st, t_ptr);

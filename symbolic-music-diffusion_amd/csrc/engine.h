@@ -90,6 +90,9 @@ class SmdEngine {
   int refresh_weights(hipStream_t st);                       // fp32 master -> bf16 pack
   // model(x, cond): x fp32 [B][S][C], noise_level [B] -> eps_hat fp32 [B][S][C]
   int forward(const float* x, const float* noise_level, float* eps_out, hipStream_t st);
+  // the same with a BATCH-UNIFORM noise level given as a device-side row index into the FiLM tables of prepare_sampler()
+  // (row r = noise level sqrt_ap[r] of the bound schedule): no FiLM generator launches, replayable from a graph
+  int forward_level(const float* x, const int* level_ptr, float* eps_out, hipStream_t st);
   // one diffusion_loss forward + backward on the bound batch; stage: 0 = all, 1 = loss+forward+output
   // stage backward (grads of params >= head_param_offset complete), 2 = stem backward
   int loss_backward(const float* x0, const int* labels, const float* eps_in, uint32_t seed_lo, uint32_t seed_hi,

@@ -635,6 +635,18 @@ int SmdEngine::forward(const float* x, const float* noise_level, float* eps_out,
   return 0;
 }
 
+int SmdEngine::forward_level(const float* x, const int* level_ptr, float* eps_out, hipStream_t st) {
+  SMD_ARG_CHECK(x && level_ptr, "forward_level: null pointer");
+  SMD_ARG_CHECK(batch_ > 0 && !training_ && film_tables_, "forward_level: bind an inference workspace and the sampler tables first");
+  const int R = rows(), C = d_.data_channels;
+  RC(launch_cast_pad_bf16(x, R, C, W.x_bf16, Cp_, st));
+  RC(run_network(level_ptr, st));
+  if (!eps_out) return 0;                 // the caller reads the engine's own output buffer (smd_engine_pred)
+  hipError_t e = hipMemcpyAsync(eps_out, W.pred, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { smd_set_error("forward_level: memcpy: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
 // ------------------------------------------------------------------ backward
 static LnArgs ln_args(const float* x, const bf16_t* xb, int rows, const LnP& p, float* params) {
   LnArgs a;

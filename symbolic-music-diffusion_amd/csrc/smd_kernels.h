@@ -261,6 +261,7 @@ struct ReverseStepArgs {
 };
 int launch_reverse_step(const ReverseStepArgs& a, hipStream_t st);
 int launch_advance_t(int* t_ptr, hipStream_t st);   // *t_ptr -= 1
+int launch_set_t(int* t_ptr, int v, hipStream_t st);   // *t_ptr = v (restart of a walk on the sampler's own stream)
 
 // Langevin update of annealed_langevin_dynamics / consistent_langevin_dynamics (utils/ebm_utils.py:131-164, 231-253)
 struct LangevinStepArgs {
@@ -283,6 +284,17 @@ struct LangevinStepArgs {
   float infill_sigma = 0.f;           // y = infill_samples + sigma * N(0,1)
   float* metrics_partial = nullptr;   // [B][3] (grad, step, noise): sums over c of sqrt(sum_s v^2 + 1e-10)
   float* collect_out = nullptr;       // [B][S][C] copy of the new state or null
+  // table mode (include/smd_hip.h smd_langevin_io): step-dependent arguments from device tables indexed by *k_ptr
+  const float* step_table = nullptr;  // [n][4] alpha, noise_coef, infill_sigma, sigma of the next update
+  const int32_t* slot_table = nullptr;
+  const uint32_t* key_table = nullptr;   // [n][4] threefry noise key | infill key
+  int32_t* k_ptr = nullptr;
+  uint32_t* arrive = nullptr;
+  float* collection = nullptr;
+  float* sigma_out = nullptr;
+  int n_steps = 0;
+  int32_t* level_out = nullptr;       // FiLM-table row of the next forward: min((k + 1) / steps_per_level, n_levels - 1)
+  int steps_per_level = 1, n_levels = 1;
 };
 int launch_langevin_step(const LangevinStepArgs& a, hipStream_t st);
 

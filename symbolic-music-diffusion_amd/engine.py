@@ -190,6 +190,27 @@ class Engine:
         _lib.check(self.L.smd_engine_bind_schedule(self.h, _ptr(t["coef"]), _ptr(t["sqrt_ap"]), _ptr(t["ape"]),
                                                    _ptr(t["film"])), "bind_schedule")
 
+    def set_noise_levels(self, levels: np.ndarray) -> bool:
+        """FiLM tables for an arbitrary list of batch-uniform noise levels (the sigma schedule of the Langevin samplers):
+        row r of the tables = level r.  Returns False when the list does not fit the engine's table (num_timesteps rows).
+        Replaces the bound DDPM schedule (``betas`` becomes None, so the DDPM sampler rebinds its own)."""
+        levels = np.asarray(levels, dtype=np.float32).reshape(-1)
+        T = self.cfg.num_timesteps
+        if len(levels) > T:
+            return False
+        lv = np.full((T,), levels[-1], dtype=np.float32)
+        lv[:len(levels)] = levels
+        dev = self.device
+        t = dict(coef=torch.zeros(T, 8, dtype=torch.float32, device=dev), sqrt_ap=torch.from_numpy(lv).to(dev),
+                 ape=torch.ones(T + 1, dtype=torch.float32, device=dev),
+                 slot=torch.full((T,), -1, dtype=torch.int32, device=dev),
+                 film=torch.zeros(int(self.L.smd_engine_film_table_floats(self.h)), dtype=torch.float32, device=dev))
+        self._sched_tensors, self.betas = t, None
+        _lib.check(self.L.smd_engine_bind_schedule(self.h, _ptr(t["coef"]), _ptr(t["sqrt_ap"]), _ptr(t["ape"]), _ptr(t["film"])),
+                   "bind_schedule")
+        self.prepare_sampler()
+        return True
+
     def bind(self, batch: int, training: bool) -> None:
         if self.workspace is not None and self.batch == batch and self.training == training:
             return

@@ -48,10 +48,13 @@ class LangevinIO(C.Structure):
                 ("seed_lo", c_u32), ("seed_hi", c_u32), ("step", c_u32), ("sample_offset", c_u32), ("use_threefry", c_i32),
                 ("tf_noise_key", c_u32 * 2), ("tf_infill_key", c_u32 * 2), ("tf_n_total", c_i64),
                 ("infill_samples", c_void), ("infill_masks", c_void), ("infill_z_in", c_void), ("infill_sigma", C.c_float),
-                ("metrics_partial", c_void), ("collect_out", c_void)]
+                ("metrics_partial", c_void), ("collect_out", c_void),
+                ("step_table", c_void), ("slot_table", c_void), ("key_table", c_void), ("k_ptr", c_void), ("arrive", c_void),
+                ("collection", c_void), ("sigma_out", c_void), ("n_steps", c_i32), ("level_out", c_void),
+                ("steps_per_level", c_i32), ("n_levels", c_i32)]
 
 
-ABI_VERSION = 2          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
+ABI_VERSION = 3          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
 
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
 _SIGS = {
@@ -75,6 +78,7 @@ _SIGS = {
     "smd_engine_bind_schedule": (C.c_int, [c_void] * 5),
     "smd_engine_refresh_weights": (C.c_int, [c_void, c_void]),
     "smd_engine_forward": (C.c_int, [c_void] * 5),
+    "smd_engine_forward_level": (C.c_int, [c_void] * 5),
     "smd_engine_loss_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_u32, c_u32, c_u32, C.c_float,
                                            C.c_int, c_void]),
     "smd_engine_set_used_alphas": (C.c_int, [c_void, c_void]),
@@ -88,6 +92,7 @@ _SIGS = {
     "smd_engine_load_state": (C.c_int, [c_void, c_void, c_void]),
     "smd_engine_sample_step": (C.c_int, [c_void, C.POINTER(SampleIO), c_void]),
     "smd_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
+    "smd_set_timestep": (C.c_int, [c_void, c_i32, c_void]),
     "smd_gemm_bf16_nt": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, C.c_int, c_void, C.c_int, c_void, C.c_int, c_void]),
     "smd_quantize_rows_e4m3": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),

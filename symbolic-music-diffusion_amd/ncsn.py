@@ -278,10 +278,76 @@ def _langevin_io(x, grad, alpha, noise_coef, rng, step, sample_offset, metrics, 
     return io
 
 
+def _langevin_graph_loop(model: "Model", x: torch.Tensor, io: "_lib.LangevinIO", step_rows: np.ndarray, slots: Optional[np.ndarray],
+                         keys: Optional[np.ndarray], metrics: torch.Tensor, collection: Optional[torch.Tensor], use_graph: bool,
+                         levels: Optional[np.ndarray] = None, steps_per_level: int = 1) -> None:
+    """All ``n = len(step_rows)`` Langevin updates of a run as ONE captured (eps-net forward + fused update) pair replayed
+    n - 1 times: the step-dependent arguments (alpha, noise coefficient, infill sigma, the next forward's noise level,
+    collection slot, threefry keys) live in device tables indexed by a device-side counter the update kernel advances
+    (csrc/diffusion.hip langevin_step_kernel, table mode), exactly as the DDPM sampler keeps t on the device."""
+    eng = model.engine
+    dev = eng.device
+    B, S, Cn = x.shape[0], eng.S, eng.C
+    n = int(step_rows.shape[0])
+    eng.bind(B, training=False)
+    eng._sync_fp8_weights()
+    # the noise level is batch-uniform inside both samplers: FiLM scale / shift of every level are tabulated once (as the
+    # DDPM sampler does for its T levels) and the forward pass takes the level as a device-side table row
+    by_level = levels is not None and eng.set_noise_levels(levels)
+    level_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    tab = torch.from_numpy(np.ascontiguousarray(step_rows[:, :4], dtype=np.float32)).to(dev)
+    slot_t = None if slots is None else torch.from_numpy(np.ascontiguousarray(slots, dtype=np.int32)).to(dev)
+    key_t = None if keys is None else torch.from_numpy(np.ascontiguousarray(keys).view(np.int32).copy()).to(dev)
+    k_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+    arrive = torch.zeros(1, dtype=torch.int32, device=dev)
+    sig_vec = torch.full((B,), float(step_rows[0, 4]), dtype=torch.float32, device=dev)       # noise level of update 0's forward
+    grad = None if by_level else torch.empty_like(x)          # by level: the update reads the engine's output buffer in place
+    io.x = x.data_ptr()
+    io.grad = int(_lib.get_lib().smd_engine_pred(eng.h)) if by_level else grad.data_ptr()
+    io.step_table, io.n_steps = tab.data_ptr(), n
+    io.slot_table = None if slot_t is None else slot_t.data_ptr()
+    io.key_table = None if key_t is None else key_t.data_ptr()
+    io.k_ptr, io.arrive = k_ptr.data_ptr(), arrive.data_ptr()
+    io.collection = None if collection is None else collection.data_ptr()
+    io.sigma_out = sig_vec.data_ptr()
+    io.metrics_partial = metrics.data_ptr()
+    if by_level:
+        io.level_out, io.steps_per_level, io.n_levels = level_ptr.data_ptr(), int(steps_per_level), int(len(levels))
+    L_ = _lib.get_lib()
+
+    def one():
+        st = torch.cuda.current_stream(dev).cuda_stream
+        if by_level:
+            _lib.check(L_.smd_engine_forward_level(eng.h, x.data_ptr(), level_ptr.data_ptr(), None, st), "forward_level")
+        else:
+            _lib.check(L_.smd_engine_forward(eng.h, x.data_ptr(), sig_vec.data_ptr(), grad.data_ptr(), st), "forward")
+        _lib.check(L_.smd_langevin_step(C.byref(io), B, S, Cn, st), "langevin_step")
+
+    with torch.cuda.device(dev):
+        if not use_graph or n < 3:
+            for _ in range(n):
+                one()
+            return
+        cur = torch.cuda.current_stream(dev)
+        st = torch.cuda.Stream(device=dev)
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            one()                                                  # update 0 (also the warm-up of the capture)
+        st.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            one()
+        with torch.cuda.stream(st):
+            for _ in range(n - 1):
+                g.replay()
+        cur.wait_stream(st)
+    torch.cuda.current_stream(dev).synchronize()                   # the tables / counters above go out of scope
+
+
 def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon, T, denoise, infill=False,
                                infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
                                infill_noises: Optional[Callable] = None, sample_offset: int = 0,
-                               global_num_samples: Optional[int] = None):
+                               global_num_samples: Optional[int] = None, use_graph: bool = True):
     """utils/ebm_utils.py:89-198.  Returns (state, collection (100 + 1 + int(denoise), ...), ld_metrics (4, L, T)).
 
     Per update: grad = model(state, sigma) through the engine, then ONE fused kernel (csrc/diffusion.hip
@@ -318,7 +384,32 @@ def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon
     zbuf = torch.zeros_like(x) if noises is not None else None
     izbuf = torch.zeros_like(x) if (infill and infill_noises is not None) else None
     sig_vec = torch.empty((B,), dtype=torch.float32, device=dev)
-    for si in range(L):
+    if noises is None and infill_noises is None:
+        # no explicit draws: every update's arguments go into device tables and the whole run is one replayed graph
+        rows = np.zeros((L * T, 5), dtype=np.float32)      # alpha, sqrt(2 alpha), infill sigma, NEXT forward's sigma | own sigma
+        slots = np.full((L * T,), -1, dtype=np.int32)
+        for si in range(L):
+            sigma = np.float32(sig[si])
+            alpha = np.float32(epsilon) * (sigma / np.float32(sig[-1])) ** 2     # :168
+            alphas[si] = alpha
+            for i in range(T):
+                k = si * T + i
+                nxt = np.float32(sig[min(L - 1, (k + 1) // T)])
+                rows[k] = (alpha, np.sqrt(np.float32(2) * alpha), sigma, nxt, sigma)
+                slot = ald_collection_slot(cidx, k + 1)                           # :149-156 (duplicates add up, as upstream)
+                slots[k] = slot if 0 < slot < n_coll else -1
+        io = _lib.LangevinIO()
+        io.seed_lo, io.seed_hi = rng.seed & 0xFFFFFFFF, (rng.seed >> 32) & 0xFFFFFFFF
+        io.sample_offset = int(sample_offset)
+        keys = None
+        if jax_mode:
+            io.use_threefry, io.tf_n_total = 1, n_glob
+            keys = np.concatenate([np.asarray(step_keys, dtype=np.uint32), np.asarray(infill_keys, dtype=np.uint32)], axis=1)
+        if inf_m is not None:
+            io.infill_samples, io.infill_masks = inf_s.data_ptr(), inf_m.data_ptr()
+        _langevin_graph_loop(model, x, io, rows, slots, keys, metrics, collection, use_graph, levels=sig, steps_per_level=T)
+    else:
+      for si in range(L):
         sigma = np.float32(sig[si])
         alpha = np.float32(epsilon) * (sigma / np.float32(sig[-1])) ** 2         # :168
         alphas[si] = alpha
@@ -338,11 +429,6 @@ def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon
                 if izbuf is not None:
                     izbuf.copy_(torch.as_tensor(infill_noises(si, i)).to(dev, torch.float32))
                     io.infill_z_in = izbuf.data_ptr()
-            if jax_mode:
-                io.use_threefry = 1
-                io.tf_noise_key[0], io.tf_noise_key[1] = int(step_keys[k, 0]), int(step_keys[k, 1])
-                io.tf_infill_key[0], io.tf_infill_key[1] = int(infill_keys[k, 0]), int(infill_keys[k, 1])
-                io.tf_n_total = n_glob
             with torch.cuda.device(dev):
                 _lib.check(_lib.get_lib().smd_langevin_step(C.byref(io), B, S, Cn, torch.cuda.current_stream().cuda_stream),
                            "langevin_step")
@@ -361,7 +447,7 @@ def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon
 
 def consistent_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon, T=None, denoise=True, infill=False,
                                  infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
-                                 sample_offset: int = 0, global_num_samples: Optional[int] = None):
+                                 sample_offset: int = 0, global_num_samples: Optional[int] = None, use_graph: bool = True):
     """utils/ebm_utils.py:201-271: one update per noise level, noise = beta * sigma_{i+1} * z.  Returns
     (state, ld_metrics (4, L, 1)) like the reference (two values; T is a null parameter there too)."""
     del T, infill_samples, infill_masks
@@ -385,7 +471,23 @@ def consistent_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsil
         n_glob = (B + sample_offset if global_num_samples is None else int(global_num_samples)) * per
     zbuf = torch.zeros_like(x) if noises is not None else None
     sig_vec = torch.empty((B,), dtype=torch.float32, device=dev)
-    for i in range(L):
+    if noises is None:                  # one captured (forward + update) pair replayed for every noise level
+        rows = np.zeros((L, 5), dtype=np.float32)
+        for i in range(L):
+            sigma = f(sig[i])
+            next_sigma = f(sig[i + 1]) if i < L - 1 else f(0)                      # :236
+            alphas[i] = f(epsilon) * (sigma / f(sig[-1])) ** 2                     # :238
+            rows[i] = (alphas[i], beta * next_sigma, 0.0, f(sig[min(i + 1, L - 1)]), sigma)
+        io = _lib.LangevinIO()
+        io.seed_lo, io.seed_hi = rng.seed & 0xFFFFFFFF, (rng.seed >> 32) & 0xFFFFFFFF
+        io.sample_offset = int(sample_offset)
+        keys = None
+        if jax_mode:
+            io.use_threefry, io.tf_n_total = 1, n_glob
+            keys = np.concatenate([np.asarray(step_keys, dtype=np.uint32), np.zeros((L, 2), np.uint32)], axis=1)
+        _langevin_graph_loop(model, x, io, rows, None, keys, metrics, None, use_graph, levels=sig, steps_per_level=1)
+    else:
+      for i in range(L):
         sigma = f(sig[i])
         next_sigma = f(sig[i + 1]) if i < L - 1 else f(0)                          # :236
         alpha = f(epsilon) * (sigma / f(sig[-1])) ** 2                             # :238
@@ -393,13 +495,8 @@ def consistent_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsil
         sig_vec.fill_(float(sigma))
         grad = model(x, sig_vec)
         io = _langevin_io(x, grad, alpha, beta * next_sigma, rng, i, sample_offset, metrics[i], None)
-        if zbuf is not None:
-            zbuf.copy_(torch.as_tensor(noises(i)).to(dev, torch.float32))
-            io.z_in = zbuf.data_ptr()
-        if jax_mode:
-            io.use_threefry = 1
-            io.tf_noise_key[0], io.tf_noise_key[1] = int(step_keys[i, 0]), int(step_keys[i, 1])
-            io.tf_n_total = n_glob
+        zbuf.copy_(torch.as_tensor(noises(i)).to(dev, torch.float32))
+        io.z_in = zbuf.data_ptr()
         with torch.cuda.device(dev):
             _lib.check(_lib.get_lib().smd_langevin_step(C.byref(io), B, S, Cn, torch.cuda.current_stream().cuda_stream),
                        "langevin_step")
@@ -598,10 +695,11 @@ def sample(scorenet: Model, sigmas, rng: PRNGKey, sample_shape, num_samples=2400
         if sampling == "ald":
             generated, collection, ld = annealed_langevin_dynamics(ld_rng, scorenet, sigmas, init, epsilon, steps, denoise,
                                                                    False, sample_offset=sample_offset,
-                                                                   global_num_samples=global_num_samples)
+                                                                   global_num_samples=global_num_samples, use_graph=use_graph)
         else:
             generated, ld = consistent_langevin_dynamics(ld_rng, scorenet, sigmas, init, epsilon, steps, denoise, False,
-                                                         sample_offset=sample_offset, global_num_samples=global_num_samples)
+                                                         sample_offset=sample_offset, global_num_samples=global_num_samples,
+                                                         use_graph=use_graph)
             collection = torch.stack([init, generated])
         return generated, collection, collate_sampling_metrics(ld.cpu().numpy())
     eng.bind(num_samples, training=False)

@@ -199,3 +199,36 @@ def test_annealed_langevin_reference_streams_and_sample_api():
     assert rel(b, a[1:]) < 1e-4                                              # Philox mode is shard-invariant too
     with pytest.raises(ValueError):
         N.sample(model, sig, N.PRNGKey(1), (32, 42), num_samples=2, sampling="hmc")
+
+
+@pytest.mark.parametrize("rng_impl", ["philox", "threefry"])
+def test_langevin_graph_replay_equals_eager_launches(rng_impl):
+    """The annealed / consistent Langevin loops run as ONE captured (forward + update) pair whose step-dependent arguments
+    (alpha, noise coefficient, infill sigma, next noise level, collection slot, threefry keys) come from device tables indexed
+    by a device-side counter: the replayed graph, the same launches issued eagerly, and -- for the collection arithmetic --
+    the reference's slot rule must agree bit for bit."""
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    model = N.Model(NetConfig(data_channels=42, num_layers=2, num_heads=8, num_mlp_layers=1), "cuda:0", seed=3)
+    sig = O.create_noise_schedule(1.0, 0.05, 6, "geometric")
+    g = torch.Generator().manual_seed(2)
+    init = (torch.rand(4, 32, 42, generator=g) * 2 - 1) * 1.7
+    mask = torch.zeros(4, 32, 42)
+    mask[:, :8] = 1.0
+    kw = dict(infill=True, infill_samples=0.3 * torch.randn(4, 32, 42, generator=g), infill_masks=mask)
+    key = N.make_key(9, rng_impl)
+    for extra in ({}, kw):
+        a = N.annealed_langevin_dynamics(key, model, sig, init, 2e-5, 7, True, use_graph=True, **extra)
+        b = N.annealed_langevin_dynamics(key, model, sig, init, 2e-5, 7, True, use_graph=False, **extra)
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        x, coll, ld = a
+        assert tuple(coll.shape) == (102, 4, 32, 42) and tuple(ld.shape) == (4, 6, 7)
+        cidx = np.linspace(1, 6 * 7, 100).astype(np.int32)
+        hit = sorted({N.ald_collection_slot(cidx, k + 1) for k in range(42)} - {-1})
+        written = [r for r in range(1, 101) if float(coll[r].abs().max()) > 0]
+        assert written == [s for s in hit if 0 < s < 102]
+        assert torch.isfinite(x).all() and float(ld[2, 0, 0]) > float(ld[2, -1, 0]) > 0      # alpha shrinks with sigma
+    c1 = N.consistent_langevin_dynamics(key, model, sig, init, 2e-5, None, True, use_graph=True)
+    c2 = N.consistent_langevin_dynamics(key, model, sig, init, 2e-5, None, True, use_graph=False)
+    assert torch.equal(c1[0], c2[0]) and torch.equal(c1[1], c2[1])
