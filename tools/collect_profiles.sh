@@ -10,16 +10,16 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py --steps 50 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o t -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph > /dev/null 2> $OUT/${TAG}_kt.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt -o t -- python $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-extra-configs --no-sampler-walk --no-cpu-baseline --no-graph > /dev/null 2> $OUT/${TAG}_kt.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt/t_results.db 12 > $OUT/${TAG}_bench_kernel_trace.txt
 # per-mode traces with undistorted per-kernel times: train on ONE stream, sample step eager; the roofline microbench
 # (104 extra launches of the dominant kernel) is left out of these so that calls/step and the shares are the step's own
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train -o t -- python $R/bench.py --mode train --side-wgrad 0 --steps 10 --warmup 2 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_train.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train -o t -- python $R/bench.py --mode train --side-wgrad 0 --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_train.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt_train/t_results.db 12 > $OUT/${TAG}_train_single_stream_kernel_trace.txt
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_sample -o t -- python $R/bench.py --mode sample --steps 10 --warmup 2 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_sample.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_sample -o t -- python $R/bench.py --mode sample --steps 10 --warmup 2 --repeats 1 --no-sampler-walk --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_sample.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt_sample/t_results.db 12 > $OUT/${TAG}_sample_kernel_trace.txt
 # the default two-stream train step without the microbench (critical-path analysis: tools/stream_busy.py)
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train2 -o t -- python $R/bench.py --mode train --steps 10 --warmup 2 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_train2.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_kt_train2 -o t -- python $R/bench.py --mode train --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-graph --no-roofline-microbench > /dev/null 2> $OUT/${TAG}_kt_train2.err
 python $R/tools/prof_summary.py $OUT/${TAG}_kt_train2/t_results.db 12 > $OUT/${TAG}_train_two_stream_kernel_trace.txt
 python $R/tools/stream_busy.py $OUT/${TAG}_kt_train2/t_results.db > $OUT/${TAG}_train_stream_busy.txt
 cp $OUT/${TAG}_kt_train/t_results.db $OUT/${TAG}_train.db; cp $OUT/${TAG}_kt_sample/t_results.db $OUT/${TAG}_sample.db
