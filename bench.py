@@ -177,6 +177,7 @@ class Workload:
                         **NET_KW[cfg_name])
         self.cfg = cfg
         self.model = model = N.Model(cfg, dev, seed=0)
+        model._chain_streams = chain_streams(torch, dev, 2)        # every model of this process walks its chains on the same pair
         self.betas = betas = S.create_noise_schedule(1e-6, 0.01, 1000, "linear")
         B = self.B = a.batch
         if comm is not None:
