@@ -353,3 +353,19 @@ def test_cli_objective_and_sampler_gates():
         sm.main(["sample_ncsn.py", "--sampling=hmc", "--synthetic"])
     with pytest.raises(SystemExit, match="DDPM mode"):
         sm.main(["sample_ncsn.py", "--sampling=ald", "--interpolate", "--synthetic"])
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`bench.py --gpus N` launches its own N ranks; on a box with fewer GPUs it must fail loudly instead of running one rank and
+    printing n_gpus: 1 (the driver invokes it exactly like this).  A WORLD_SIZE that disagrees with --gpus is refused too."""
+    import subprocess
+    import sys
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have >= 2:
+        pytest.skip("a multi-GPU box would really launch the ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "needs 2 GPUs" in (r.stderr + r.stdout) and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="4", RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout) and r.stdout.strip() == ""
