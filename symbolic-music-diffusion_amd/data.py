@@ -88,8 +88,10 @@ class ArrayLatents:
                  drop_remainder: bool = True, device: Optional[str] = None, rank: int = 0, world_size: int = 1,
                  shuffle: bool = False, seed: int = 0):
         """``shuffle``: a fresh seeded permutation of the WHOLE split every epoch (the reference reshuffles its files and an
-        8*batch buffer per epoch, utils/data_utils.py:159-183); with world_size > 1 every rank holds the split and takes
-        its own slice of the same global permutation, so the ranks stay disjoint.  Unshuffled: one contiguous shard."""
+        8*batch buffer per epoch, utils/data_utils.py:159-183); with world_size > 1 every rank takes its own slice of the same
+        global permutation, so the ranks stay disjoint: the split then stays in (pinned) HOST memory and only this rank's
+        1 / world_size of the epoch is gathered and copied to the device, once per epoch (no per-step copies, 1 / world_size of the
+        HBM footprint).  Unshuffled: one contiguous shard."""
         array = np.ascontiguousarray(array, dtype=np.float32)
         self.shuffle, self.seed, self.epoch = bool(shuffle), int(seed), 0
         self.rank, self.world_size = int(rank), int(world_size)
@@ -97,7 +99,14 @@ class ArrayLatents:
         if world_size > 1 and not shuffle:      # disjoint contiguous shard per rank
             array = array[rank * per:(rank + 1) * per]
         self.array = torch.from_numpy(array)
-        if device is not None:
+        self.device = device
+        self.host_resident = bool(shuffle) and world_size > 1 and device is not None
+        if self.host_resident:
+            try:
+                self.array = self.array.pin_memory()
+            except Exception:            # no accelerator runtime (CPU-only tests): pageable memory works the same
+                pass
+        elif device is not None:
             self.array = self.array.to(device)   # resident in HBM: no per-step H2D copy
         self.batch_size = batch_size
         self.per_rank = per
@@ -123,8 +132,14 @@ class ArrayLatents:
             for i in range(self.examples):
                 yield self.array[i * self.batch_size:(i + 1) * self.batch_size]
             return
-        idx = self.epoch_order(self.epoch).to(self.array.device)
+        idx = self.epoch_order(self.epoch)
         self.epoch += 1
+        if self.host_resident:           # this rank's share of the epoch: one gather on the host, one H2D copy
+            shard = self.array.index_select(0, idx).to(self.device, non_blocking=True)
+            for i in range(self.examples):
+                yield shard[i * self.batch_size:(i + 1) * self.batch_size]
+            return
+        idx = idx.to(self.array.device)
         for i in range(self.examples):
             yield self.array.index_select(0, idx[i * self.batch_size:(i + 1) * self.batch_size])
 
