@@ -495,8 +495,18 @@ struct MlpHsArgs {
   int dbg;
 };
 
-template <int NS>
+// TS instantiation (tuning knob mlp_hs_dbg = 64, tools/mlp_hs_phases.py): every wave stamps s_memtime at its phase boundaries
+// -- behind an explicit wait for what the phase issued -- and leaves the stamps in its partial tile instead of the result.
+#define HS_TS(i)                                                             \
+  if constexpr (TS) {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    ts[i] = (uint32_t)__builtin_amdgcn_s_memtime();                          \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+  }
+template <int NS, bool TS = false>
 __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
+  uint32_t ts[36];
+  HS_TS(0)
   __shared__ __attribute__((aligned(16))) unsigned char smem[HS_TILE + NS * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -556,14 +566,19 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
       for (int e = 0; e < 4; ++e) acc[s][mt][e] = 0.0f;
 
   const int arow = (hg * 32 + j) * 256;                    // A-fragment row of this lane inside a slice (m-tile 0)
-  for (int c = 0; c < ((a.dbg & 1) ? 0 : nchunks); ++c) {
+  HS_TS(1)
+  const int nloop = TS ? 4 : ((a.dbg & 1) ? 0 : nchunks);  // TS: constant stamp indices (the launcher checks hidden = 2048)
+#pragma unroll
+  for (int c = 0; c < nloop; ++c) {
     const int buf = c & 1;
+    HS_TS(2 + c * 8)
     // The W1 slice of chunk c has landed (vmcnt(4): its W2 slice, issued right behind it, may still be in flight: it
     // is only needed after the second barrier); every wave is done with iteration c-1, so the other weight buffer and
     // the u tiles are free (the first pass also orders the a2 fragment reads before the u writes).
     asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    HS_TS(3 + c * 8)
     const float4 bcur[2] = {bnext[0], bnext[1]};
     const bool more = c + 1 < nchunks;
     if (more) {
@@ -579,6 +594,8 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) wf[mt][ks] = *reinterpret_cast<lds_b128_ptr>(s1 + arow + mt * 16 * 256 + (((ks * 4 + g) ^ j) << 4));
+      if constexpr (TS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      HS_TS(4 + c * 8)
       f32x4_t z[NS][2];
 #pragma unroll
       for (int s = 0; s < NS; ++s)
@@ -592,6 +609,13 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
         for (int s = 0; s < NS; ++s)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) z[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][ks], a2f[s][ks], z[s][mt], 0, 0, 0);
+      if constexpr (TS) {                  // the last MFMA of every accumulator has retired
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) asm volatile("v_mov_b32 %0, %0" : "+v"(z[s][mt][0]));
+      }
+      HS_TS(5 + c * 8)
       // + b1, GELU -> u[sample][token][hidden] (hidden of z[s][mt][e]: hg*32 + mt*16 + 4g + e)
 #pragma unroll
       for (int s = 0; s < NS; ++s)
@@ -605,11 +629,14 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
           *reinterpret_cast<bf16x4_t*>(smem + HS_TILE + (s * 32 + tok) * 256 + (((hid >> 3) ^ (tok & 15)) << 4) + (hid & 7) * 2) = uu;
         }
     }
+    if constexpr (TS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    HS_TS(6 + c * 8)
     // u tiles written; the W2 slice of this chunk has landed: behind it only the next chunk's 2 bias loads + 8 DMAs
     if (more) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    HS_TS(7 + c * 8)
     {
       // ---- GEMM2: out^T tiles [16 n][16 tokens] += W2t[n][chunk] u^T
       bf16x8_t vf[2][4];
@@ -629,8 +656,16 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
           for (int mt = 0; mt < 2; ++mt) acc[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[mt][ks], uf[ks], acc[s][mt], 0, 0, 0);
       }
     }
+    if constexpr (TS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) asm volatile("v_mov_b32 %0, %0" : "+v"(acc[s][mt][0]));
+    }
+    HS_TS(8 + c * 8)
     __builtin_amdgcn_sched_barrier(0);
   }
+  HS_TS(34)
 
   // ---- this quarter's partial tile: out[token][n], n = hg*32 + mt*16 + 4g + e (4 consecutive per lane); quarter 0
   // carries the bias and the residual
@@ -649,8 +684,19 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
         }
         *reinterpret_cast<float4*>(dst + (size_t)(s * 32 + tok) * E_DIM + n0) = v;
       }
+    if constexpr (TS) {                    // 36 stamps per wave at the head of the workgroup's partial tile (40 dwords apart)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      HS_TS(35)
+      __syncthreads();
+      if (lane == 0) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst) + w * 40;
+#pragma unroll
+        for (int i = 0; i < 36; ++i) d[i] = ts[i];
+      }
+    }
   }
 }
+#undef HS_TS
 
 // x = (p0 + p1) + (p2 + p3) of four partial tiles (one wave per 128-wide row), optionally written out, optionally
 // followed by LayerNorm -> bf16: the consumer of the hidden-split MLP's output where no attention kernel follows
@@ -1555,7 +1601,10 @@ int launch_mlp_block_fwd_hs(const bf16_t* a2, const float* h_res, int rows, cons
   a.a2 = a2; a.h_res = h_res; a.W1t = W1t; a.b1 = b1; a.W2t = W2t; a.b2 = b2; a.M = M; a.part = part; a.rows = rows;
   a.dbg = smd_tuning_get("mlp_hs_dbg");
   const dim3 grid((rows / (S_TOK * ns)) * HS_NQ), block(512);
-  if (ns == 4) hipLaunchKernelGGL(mlp_hs_fwd_kernel<4>, grid, block, 0, st, a);
+  if (a.dbg & 64) {                // phase stamps instead of the result (tools/mlp_hs_phases.py)
+    SMD_ARG_CHECK(ns == 4 && M == 2048, "mlp_block_fwd_hs: the instrumented instantiation is built for groups of 4 samples, hidden 2048");
+    hipLaunchKernelGGL((mlp_hs_fwd_kernel<4, true>), grid, block, 0, st, a);
+  } else if (ns == 4) hipLaunchKernelGGL(mlp_hs_fwd_kernel<4>, grid, block, 0, st, a);
   else if (ns == 2) hipLaunchKernelGGL(mlp_hs_fwd_kernel<2>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(mlp_hs_fwd_kernel<1>, grid, block, 0, st, a);
   SMD_LAUNCH_CHECK();
