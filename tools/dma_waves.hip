@@ -2,6 +2,8 @@
 // in flight: no MFMA, no LDS reads; every workgroup streams its own contiguous 8 MiB of a 2 GiB buffer (HBM, single use)
 // through a ring in LDS.  Measured (profiles/r2q_dma_waves.txt): 23.3-23.6 GB/s per CU = 6.0 TB/s over the chip for 4, 8
 // and 16 waves and 2 or 4 tiles in flight alike -- the HBM roof of this path; wave count and depth are not the lever.
+// Second part (round 3): every workgroup walks the SAME small region again and again (1 MiB: L2-resident like a weight panel;
+// 16 MiB: Infinity-Cache-resident) -- the ceiling of the shared-operand path the GEMM / fused-encoder kernels use.
 //   build: hipcc -O3 --offload-arch=gfx950 tools/dma_waves.hip -o tools/dma_waves     run: tools/dma_waves
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,13 +16,16 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // NW waves; each wave issues PIECES 1-KiB DMA instructions per tile (tile = NW * PIECES KiB) and keeps DEPTH tiles in flight
 template <int NW, int PIECES, int DEPTH>
 __global__ __launch_bounds__(64 * NW) void dma_stream(const unsigned char* __restrict__ src, size_t bytes_per_wg, int tiles,
-                                                     unsigned* __restrict__ sink) {
+                                                     unsigned* __restrict__ sink, int wrap_tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int TILE = NW * PIECES * 1024;
-  const unsigned char* base = src + (size_t)blockIdx.x * bytes_per_wg + (size_t)w * PIECES * 1024 + lane * 16;
-  auto issue = [&](int t, int buf) {
+  // wrap_tiles > 0: all workgroups share one region of wrap_tiles tiles (each starts at its own tile of it)
+  const unsigned char* base = src + (wrap_tiles ? 0 : (size_t)blockIdx.x * bytes_per_wg) + (size_t)w * PIECES * 1024 + lane * 16;
+  const int t0 = wrap_tiles ? (int)(blockIdx.x * 7u) : 0;
+  auto issue = [&](int tt, int buf) {
+    const int t = wrap_tiles ? (tt + t0) % wrap_tiles : tt;
 #pragma unroll
     for (int p = 0; p < PIECES; ++p)
       __builtin_amdgcn_global_load_lds((glb_void_t*)(base + (size_t)t * TILE + p * 1024),
@@ -43,20 +48,21 @@ __global__ __launch_bounds__(64 * NW) void dma_stream(const unsigned char* __res
 }
 
 template <int NW, int PIECES, int DEPTH>
-static void run(const unsigned char* d_src, size_t total, unsigned* d_sink, const char* what) {
+static void run(const unsigned char* d_src, size_t total, unsigned* d_sink, const char* what, size_t region = 0) {
   constexpr int TILE = NW * PIECES * 1024;
   const int nwg = 256;
   const size_t per = total / nwg / TILE * TILE;
   const int tiles = (int)(per / TILE);
+  const int wrap_tiles = (int)(region / TILE);
   const size_t lds = (size_t)DEPTH * TILE;
   if (lds > 160 * 1024) { printf("%-52s skipped (%zu KiB LDS)\n", what, lds / 1024); return; }
   hipFuncSetAttribute((const void*)dma_stream<NW, PIECES, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((dma_stream<NW, PIECES, DEPTH>), dim3(nwg), dim3(64 * NW), lds, 0, d_src, per, tiles, d_sink);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((dma_stream<NW, PIECES, DEPTH>), dim3(nwg), dim3(64 * NW), lds, 0, d_src, per, tiles, d_sink, wrap_tiles);
   hipEventRecord(e0);
   const int reps = 5;
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((dma_stream<NW, PIECES, DEPTH>), dim3(nwg), dim3(64 * NW), lds, 0, d_src, per, tiles, d_sink);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((dma_stream<NW, PIECES, DEPTH>), dim3(nwg), dim3(64 * NW), lds, 0, d_src, per, tiles, d_sink, wrap_tiles);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -81,6 +87,14 @@ int main() {
   run<16, 2, 4>(d_src, total, d_sink, "16 waves x 2 KiB per tile, 4 tiles deep");
   run<16, 4, 2>(d_src, total, d_sink, "16 waves x 4 KiB per tile, 2 tiles deep");
   run<16, 4, 2>(d_src, total, d_sink, "16 waves x 4 KiB per tile, 2 tiles deep (repeat)");
+  printf("the same 8 MiB of DMA per workgroup, but every workgroup walks ONE shared region (operand panels)\n");
+  run<8, 8, 2>(d_src, total, d_sink, " 8 waves x 8 KiB, 2 deep, shared  1 MiB (L2)", (size_t)1 << 20);
+  run<8, 4, 4>(d_src, total, d_sink, " 8 waves x 4 KiB, 4 deep, shared  1 MiB (L2)", (size_t)1 << 20);
+  run<4, 8, 4>(d_src, total, d_sink, " 4 waves x 8 KiB, 4 deep, shared  1 MiB (L2)", (size_t)1 << 20);
+  run<16, 4, 2>(d_src, total, d_sink, "16 waves x 4 KiB, 2 deep, shared  1 MiB (L2)", (size_t)1 << 20);
+  run<8, 8, 2>(d_src, total, d_sink, " 8 waves x 8 KiB, 2 deep, shared  8 MiB (L2 of all XCDs together / MALL)", (size_t)8 << 20);
+  run<8, 8, 2>(d_src, total, d_sink, " 8 waves x 8 KiB, 2 deep, shared 64 MiB (MALL)", (size_t)64 << 20);
+  run<8, 8, 2>(d_src, total, d_sink, " 8 waves x 8 KiB, 2 deep, shared  1 MiB (repeat)", (size_t)1 << 20);
   hipFree(d_src); hipFree(d_sink);
   return 0;
 }
