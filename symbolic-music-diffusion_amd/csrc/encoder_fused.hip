@@ -424,41 +424,30 @@ __global__ __launch_bounds__(512) void mlp_block_fwd8_kernel(MlpArgs a) {
 }
 
 // All-reduce of R independent values per lane over the 64 lanes of a wave; the R chains are interleaved step by
-// step so that the exchange latencies overlap.  Default: six xor exchanges through the LDS crossbar (ds_bpermute,
-// __shfl_xor) -- every step adds two commuting operands, so all lanes end with the bitwise identical sum.
-// SMD_ALLREDUCE_DPP (experiment builds only): the four intra-row steps as DPP operations,
-//   1 = as hipcc schedules them (dependent DPP reads at the hazard recognizer's minimum distance of two wait states),
-//   2 = every DPP step preceded by s_nop 4 inside one asm statement.
-#ifndef SMD_ALLREDUCE_DPP
-#define SMD_ALLREDUCE_DPP 0
-#endif
-template <int R>
+// step so that the exchange latencies overlap.  Every step adds two commuting operands, so all lanes end with the bitwise
+// identical sum, and the DPP and the ds_bpermute form of a step give the same bits.
+//   DPP = 0: six xor exchanges through the LDS crossbar (ds_bpermute, __shfl_xor): 6 R LDS-pipe operations per wave.
+//   DPP = 1: the four intra-row steps as DPP moves on the VALU (quad_perm, row_half_mirror, row_mirror), the two cross-row
+//            steps through the crossbar: 2 R LDS-pipe operations.  (The round-2 suspicion against the DPP form was cleared in
+//            round 3: the reduction primitive is innocent of the co-residency miscompare)
+template <int R, int DPP = 0>
 __device__ __forceinline__ void wave_allreduce_sum(float (&v)[R]) {
-#if SMD_ALLREDUCE_DPP == 1
+  if constexpr (DPP == 1) {
 #define SMD_DPP_ADD(CTRL)                                                                                          \
   _Pragma("unroll") for (int i = 0; i < R; ++i)                                                                    \
     v[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[i]), CTRL, 0xF, 0xF, true));
-  SMD_DPP_ADD(0xB1)    // quad_perm [1,0,3,2]
-  SMD_DPP_ADD(0x4E)    // quad_perm [2,3,0,1]
-  SMD_DPP_ADD(0x141)   // row_half_mirror
-  SMD_DPP_ADD(0x140)   // row_mirror
+    SMD_DPP_ADD(0xB1)    // quad_perm [1,0,3,2]
+    SMD_DPP_ADD(0x4E)    // quad_perm [2,3,0,1]
+    SMD_DPP_ADD(0x141)   // row_half_mirror
+    SMD_DPP_ADD(0x140)   // row_mirror
 #undef SMD_DPP_ADD
-#elif SMD_ALLREDUCE_DPP == 2
-#define SMD_DPP_ADD(CTRL)                                                                                          \
-  _Pragma("unroll") for (int i = 0; i < R; ++i)                                                                    \
-    asm volatile("s_nop 4\n\tv_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\ts_nop 1" : "+v"(v[i]));
-  SMD_DPP_ADD("quad_perm:[1,0,3,2]")
-  SMD_DPP_ADD("quad_perm:[2,3,0,1]")
-  SMD_DPP_ADD("row_half_mirror")
-  SMD_DPP_ADD("row_mirror")
-#undef SMD_DPP_ADD
-#else
+  } else {
 #pragma unroll
-  for (int o = 1; o < 16; o <<= 1) {
+    for (int o = 1; o < 16; o <<= 1) {
 #pragma unroll
-    for (int i = 0; i < R; ++i) v[i] += __shfl_xor(v[i], o, 64);
+      for (int i = 0; i < R; ++i) v[i] += __shfl_xor(v[i], o, 64);
+    }
   }
-#endif
 #pragma unroll
   for (int i = 0; i < R; ++i) v[i] += __shfl_xor(v[i], 16, 64);
 #pragma unroll
@@ -1024,9 +1013,19 @@ struct AttnArgs {
   const float* gamma2; const float* beta2; bf16_t* a2_out;
 };
 
-template <int DH>
+// TS instantiation (tuning knob mlp_hs_dbg = 128, tools/attn_phases.py): s_memtime stamps per wave at the phase boundaries, left in
+// the first rows of the workgroup's h_out tile instead of the result.
+#define AT_TS(i)                                                             \
+  if constexpr (TS) {                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+    ts[i] = (uint32_t)__builtin_amdgcn_s_memtime();                          \
+    __builtin_amdgcn_sched_barrier(0);                                       \
+  }
+template <int DH, bool TS = false>
 __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[AT_SMEM];
+  uint32_t ts[16];
+  AT_TS(0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t row0 = (size_t)blockIdx.x * S_TOK;
@@ -1039,21 +1038,29 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
   const __amdgpu_buffer_rsrc_t wq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wqkv_t), 0, 384 * 256, 0x00020000);
   const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wo_t), 0, 128 * 256, 0x00020000);
   unsigned char* lds_w = smem + w * 1024;
-#pragma unroll
-  for (int j = 0; j < 24; ++j) glds16(wq_rsrc, wv, (uint32_t)(j * 4096), lds_w + AT_W + j * 4096);
-
-  // ---- LayerNorm -> a1 tile
+  // ---- LayerNorm -> a1 tile.  The input rows are requested FIRST: the phase stamps (tools/attn_phases.py) showed the 24 DMA
+  // pieces of Wqkv (~90 cycles of issue apiece, needed only behind barrier 1) in front of them delaying the whole LayerNorm.
   {
     const float2 g2 = *reinterpret_cast<const float2*>(a.gamma + lane * 2);
     const float2 b2v = *reinterpret_cast<const float2*>(a.beta + lane * 2);
     float2 x[8];
+    float2 pp[4][8];
     if (a.h_parts) {
-      float2 pp[4][8];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           pp[k][i] = *reinterpret_cast<const float2*>(a.h_parts + k * a.part_stride + (row0 + w * 8 + i) * E_DIM + lane * 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 8 + i) * E_DIM + lane * 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 24; ++j) glds16(wq_rsrc, wv, (uint32_t)(j * 4096), lds_w + AT_W + j * 4096);
+    __builtin_amdgcn_sched_barrier(0);
+    AT_TS(1)
+    if (a.h_parts) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         x[i].x = (pp[0][i].x + pp[1][i].x) + (pp[2][i].x + pp[3][i].x);
@@ -1061,14 +1068,15 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
         *reinterpret_cast<float2*>(smem + AT_XS + ((w * 8 + i) * E_DIM + lane * 2) * 4) = x[i];
         if (a.h_comb) *reinterpret_cast<float2*>(a.h_comb + (row0 + w * 8 + i) * E_DIM + lane * 2) = x[i];
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = *reinterpret_cast<const float2*>(a.h_in + (row0 + w * 8 + i) * E_DIM + lane * 2);
     }
     float st[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { st[2 * i] = x[i].x + x[i].y; st[2 * i + 1] = x[i].x * x[i].x + x[i].y * x[i].y; }
-    wave_allreduce_sum<16>(st);
+    if constexpr (TS) asm volatile("v_mov_b32 %0, %0" : "+v"(st[15]));       // the input rows have arrived
+    AT_TS(2)
+    // DPP form: 96 ds_bpermute fewer per wave, LN1 phase 4400 -> 3260 cycles (phase stamps); every value is re-read 15 DPP adds
+    // behind the instruction that wrote it
+    wave_allreduce_sum<16, 1>(st);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = w * 8 + i;
@@ -1089,8 +1097,12 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     bk[g] = *reinterpret_cast<const float4*>(a.b_qkv + 128 + w * 32 + 4 * kh + 8 * g);
   }
   const float bv = a.b_qkv[256 + w * 32 + l31];
+  if constexpr (TS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  AT_TS(3)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AT_TS(4)
   __syncthreads();
+  AT_TS(5)
 
   // a1 fragments (lane = token, k-chunk 2*ks + kh): B operand of the transposed GEMMs, A operand of the v GEMM
   bf16x8_t a1f[8];
@@ -1114,7 +1126,10 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
       cv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1f[ks], fv, cv, 0, 0, 0);
     }
   }
+  if constexpr (TS) asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %1, %1\n\tv_mov_b32 %2, %2" : "+v"(cq[0]), "+v"(ck[0]), "+v"(cv[0]));
+  AT_TS(6)
   __syncthreads();          // every wave is done reading Wqkv and a1: the regions can be reused
+  AT_TS(7)
   // Wo -> first 32 KiB of the weight region, behind the attention
 #pragma unroll
   for (int j = 0; j < 8; ++j) glds16(wo_rsrc, wv, (uint32_t)(j * 4096), lds_w + AT_W + j * 4096);
@@ -1147,6 +1162,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
   }
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-local LDS round trip (own features only)
+  AT_TS(8)
 
   // ---- attention for the heads inside this wave's 32 features
   constexpr int HPW = 32 / DH;                                 // heads per wave
@@ -1210,6 +1226,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
       }
     }
   }
+  if constexpr (TS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  AT_TS(9)
   if (a.save_qkv) {      // v, row-major, from the wave's own v^T rows: thread -> (token l31, 4 features) x 4
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1230,7 +1248,9 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     bo[g] = *reinterpret_cast<const float4*>(a.b_o + w * 32 + 4 * kh + 8 * g);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // Wo landed (and the loads above)
+  AT_TS(10)
   __syncthreads();                                             // o tile complete, Wo visible to every wave
+  AT_TS(11)
 
   // ---- out_proj^T: rows = output features (wave w: 32 of them), cols = tokens
   f32x16_t co;
@@ -1246,6 +1266,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
       co = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fo, co, 0, 0, 0);
     }
   }
+  if constexpr (TS) asm volatile("v_mov_b32 %0, %0" : "+v"(co[0]));
+  AT_TS(12)
   float4 ov[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -1257,6 +1279,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     *reinterpret_cast<float4*>(a.h_out + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g) = o;
     ov[g] = o;
   }
+  AT_TS(13)
   if (a.a2_out) {
     // ---- ln2 of the output rows: this lane holds 16 of token l31's 128 features; the other 112 sit in the other lane
     // half (xor 32) and in the other three waves (through LDS), summed in a fixed order
@@ -1271,6 +1294,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     float* stt = reinterpret_cast<float*>(smem + AT_ST);
     if (kh == 0) { stt[(w * S_TOK + l31) * 2] = ps; stt[(w * S_TOK + l31) * 2 + 1] = ps2; }
     __syncthreads();
+    AT_TS(14)
     float s = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww) { s += stt[(ww * S_TOK + l31) * 2]; s2 += stt[(ww * S_TOK + l31) * 2 + 1]; }
@@ -1288,7 +1312,18 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
       *reinterpret_cast<bf16x4_t*>(a.a2_out + (row0 + l31) * E_DIM + f) = t;
     }
   }
+  if constexpr (TS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    AT_TS(15)
+    __syncthreads();
+    if (lane == 0) {
+      uint32_t* d = reinterpret_cast<uint32_t*>(a.h_out + row0 * E_DIM) + w * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[i] = ts[i];
+    }
+  }
 }
+#undef AT_TS
 
 
 // =====================================================================================================
@@ -1668,7 +1703,10 @@ int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float
   const dim3 grid(rows / S_TOK), block(256);
   switch (num_heads) {
     case 4: hipLaunchKernelGGL(attn_block_fwd_kernel<32>, grid, block, 0, st, a); break;
-    case 8: hipLaunchKernelGGL(attn_block_fwd_kernel<16>, grid, block, 0, st, a); break;
+    case 8:
+      if (smd_tuning_get("mlp_hs_dbg") & 128) hipLaunchKernelGGL((attn_block_fwd_kernel<16, true>), grid, block, 0, st, a);   // phase stamps
+      else hipLaunchKernelGGL(attn_block_fwd_kernel<16>, grid, block, 0, st, a);
+      break;
     case 16: hipLaunchKernelGGL(attn_block_fwd_kernel<8>, grid, block, 0, st, a); break;
     default: smd_set_error("attn_block_fwd: num_heads=%d unsupported (4, 8, 16)", num_heads); return -1;
   }

@@ -1,0 +1,59 @@
+"""Where the 15 us of attn_block_fwd go: s_memtime stamps of every wave at its phase boundaries (instrumented instantiation,
+tuning knob mlp_hs_dbg = 128; the stamps replace the h_out tile).  8192 rows, 8 heads, the sampler's form of the call: input as
+four partial tiles, ln2 of the output emitted, nothing saved.
+    gpurun -- python tools/attn_phases.py > gpurun_out/<tag>_attn_phases.txt
+The tick of s_memtime differs between boxes of the pool: compare phases within one run only."""
+import os, sys, math, torch
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import smd_amd.lib as lib
+L = lib.get_lib(); dev = "cuda:0"
+rows, H = 8192, 8
+g = torch.Generator().manual_seed(0)
+parts = (torch.randn(4, rows, 128, generator=g) * 0.7).to(dev)
+gamma, beta = (1 + 0.1 * torch.randn(128, generator=g)).to(dev), (0.1 * torch.randn(128, generator=g)).to(dev)
+gamma2, beta2 = (1 + 0.1 * torch.randn(128, generator=g)).to(dev), (0.1 * torch.randn(128, generator=g)).to(dev)
+Wqkv = (torch.randn(384, 128, generator=g) * 0.09).to(torch.bfloat16).to(dev)
+Wo = (torch.randn(128, 128, generator=g) * 0.09).to(torch.bfloat16).to(dev)
+bqkv, bo = (0.1 * torch.randn(384, generator=g)).to(dev), (0.1 * torch.randn(128, generator=g)).to(dev)
+h_out = torch.empty(rows, 128, device=dev)
+a2 = torch.empty(rows, 128, dtype=torch.bfloat16, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+P = lambda t: t.data_ptr()
+
+
+def call():
+    lib.check(L.smd_attn_block_fwd_ex(None, P(parts), rows * 128, None, P(h_out), rows, P(gamma), P(beta), P(Wqkv), P(bqkv), P(Wo), P(bo),
+                                      H, P(gamma2), P(beta2), P(a2), None, None, None, st))
+
+
+def timeit(reps=40):
+    for _ in range(5):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 0))
+print(f"shipped instantiation: {sorted(timeit() for _ in range(5))[2]:.1f} us per launch (median of 5 x 40 back-to-back launches)")
+lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 128))
+print(f"instrumented:          {sorted(timeit() for _ in range(5))[2]:.1f} us")
+call()
+torch.cuda.synchronize()
+lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 0))
+raw = h_out.view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+ts = raw.reshape(rows // 32, 32 * 128)[:, :64].reshape(-1, 4, 16)              # [workgroup][wave][stamp]
+d = (ts - ts[..., 0:1]) & 0xFFFFFFFF
+names = ["start", "24 Wqkv DMA pieces issued", "input rows (4 partial tiles) arrived", "LN1 done, a1 tile written",
+         "Wqkv landed (vmcnt 0)", "barrier 1", "a1 fragments + 24 QKV MFMAs retired", "barrier 2 (+ 8 Wo DMA pieces next)",
+         "q, k, v^T written (own features)", "attention of the wave's heads, o written", "Wo + residual landed (vmcnt 0)",
+         "barrier 3", "out-proj MFMAs retired", "h_out stores issued", "LN2 statistics exchanged (barrier 4)", "a2 stored (vmcnt 0)"]
+print("ticks since the wave's first instruction: mean over 256 workgroups x 4 waves  [min .. max]  delta to previous")
+for i in range(1, 16):
+    v = d[..., i].reshape(-1)
+    print(f"  {names[i]:44s} {v.mean():8.0f}  [{v.min():6d} .. {v.max():6d}]  {(d[..., i] - d[..., i - 1]).mean():7.0f}")
