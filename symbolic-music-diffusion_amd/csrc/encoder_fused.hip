@@ -1293,7 +1293,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     ps2 += __shfl_xor(ps2, 32, 64);
     float* stt = reinterpret_cast<float*>(smem + AT_ST);
     if (kh == 0) { stt[(w * S_TOK + l31) * 2] = ps; stt[(w * S_TOK + l31) * 2 + 1] = ps2; }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the statistics only: __syncthreads() would also wait for the h_out stores
+    __builtin_amdgcn_s_barrier();
     AT_TS(14)
     float s = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1701,10 +1702,11 @@ int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float
   a.h_parts = ex ? ex->h_parts : nullptr; a.part_stride = ex ? ex->part_stride : 0; a.h_comb = ex ? ex->h_comb : nullptr;
   a.gamma2 = ex ? ex->gamma2 : nullptr; a.beta2 = ex ? ex->beta2 : nullptr; a.a2_out = ex ? ex->a2_out : nullptr;
   const dim3 grid(rows / S_TOK), block(256);
+  const bool stamps = (smd_tuning_get("mlp_hs_dbg") & 128) != 0;       // phase stamps instead of h_out (tools/attn_phases.py)
   switch (num_heads) {
     case 4: hipLaunchKernelGGL(attn_block_fwd_kernel<32>, grid, block, 0, st, a); break;
     case 8:
-      if (smd_tuning_get("mlp_hs_dbg") & 128) hipLaunchKernelGGL((attn_block_fwd_kernel<16, true>), grid, block, 0, st, a);   // phase stamps
+      if (stamps) hipLaunchKernelGGL((attn_block_fwd_kernel<16, true>), grid, block, 0, st, a);
       else hipLaunchKernelGGL(attn_block_fwd_kernel<16>, grid, block, 0, st, a);
       break;
     case 16: hipLaunchKernelGGL(attn_block_fwd_kernel<8>, grid, block, 0, st, a); break;

@@ -39,6 +39,7 @@ def timeit(reps=40):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+NW = 4
 lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 0))
 print(f"shipped instantiation: {sorted(timeit() for _ in range(5))[2]:.1f} us per launch (median of 5 x 40 back-to-back launches)")
 lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 128))
@@ -47,13 +48,17 @@ call()
 torch.cuda.synchronize()
 lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 0))
 raw = h_out.view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
-ts = raw.reshape(rows // 32, 32 * 128)[:, :64].reshape(-1, 4, 16)              # [workgroup][wave][stamp]
+ts = raw.reshape(rows // 32, 32 * 128)[:, :NW * 16].reshape(-1, NW, 16)        # [workgroup][wave][stamp]
 d = (ts - ts[..., 0:1]) & 0xFFFFFFFF
 names = ["start", "24 Wqkv DMA pieces issued", "input rows (4 partial tiles) arrived", "LN1 done, a1 tile written",
          "Wqkv landed (vmcnt 0)", "barrier 1", "a1 fragments + 24 QKV MFMAs retired", "barrier 2 (+ 8 Wo DMA pieces next)",
          "q, k, v^T written (own features)", "attention of the wave's heads, o written", "Wo + residual landed (vmcnt 0)",
          "barrier 3", "out-proj MFMAs retired", "h_out stores issued", "LN2 statistics exchanged (barrier 4)", "a2 stored (vmcnt 0)"]
-print("ticks since the wave's first instruction: mean over 256 workgroups x 4 waves  [min .. max]  delta to previous")
+print("ticks since the wave's first instruction: mean over 256 workgroups x waves 0-3  [min .. max]  delta to previous"
+      + ("   | waves 4-7: mean, delta" if NW == 8 else ""))
 for i in range(1, 16):
-    v = d[..., i].reshape(-1)
-    print(f"  {names[i]:44s} {v.mean():8.0f}  [{v.min():6d} .. {v.max():6d}]  {(d[..., i] - d[..., i - 1]).mean():7.0f}")
+    v = d[:, :4, i].reshape(-1)
+    line = f"  {names[i]:44s} {v.mean():8.0f}  [{v.min():6d} .. {v.max():6d}]  {(d[:, :4, i] - d[:, :4, i - 1]).mean():7.0f}"
+    if NW == 8 and i not in (12, 13):
+        line += f"   | {d[:, 4:, i].mean():8.0f} {(d[:, 4:, i] - d[:, 4:, i - 1 if i != 14 else 11]).mean():7.0f}"
+    print(line)
