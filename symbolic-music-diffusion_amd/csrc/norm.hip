@@ -754,9 +754,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
   smd_load_settle();
   // all-reduce over the 16 lanes of a row: four xor exchanges (__shfl_xor = ds_bpermute); every step adds two commuting
   // operands, so all 16 lanes end with the bitwise identical sum.  Until round 3 these were DPP row operations
-  // (quad_perm / row_half_mirror / row_mirror): a DPP instruction reads its source two wait states behind the VALU
-  // instruction that wrote it, and with a weight-gradient wave on the same SIMD that distance is not always enough --
-  // lanes 48..63 then take the stale register.  SMD_NARROW_DPP=1 rebuilds the DPP form for the A/B.
+  // (quad_perm / row_half_mirror / row_mirror), suspected of the co-residency miscompare while it was being hunted; the
+  // root cause turned out to be the v_rsq_f32 behind the instruction writing its source (smd_ln_rstd)
+  // and both reduction forms behaved alike in those runs.  SMD_NARROW_DPP=1 rebuilds the DPP form for the A/B.
 #ifndef SMD_NARROW_DPP
 #define SMD_NARROW_DPP 0
 #endif
