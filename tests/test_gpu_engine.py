@@ -119,6 +119,41 @@ def test_loss_and_gradient_parity(arch, C, L, H, K, tr):
     assert worst < 6e-2                                        # small bias tensors carry the most bf16 noise
 
 
+@pytest.mark.parametrize("B", [5, 7, 12])
+def test_loss_and_gradient_parity_at_odd_batch_sizes(B):
+    """Batch sizes that leave the shapes the fused encoder paths are built for: B = 5 / 7 (160 / 224 token rows: the hidden-split
+    MLP forward runs one sample per group, the backward falls back to the unfused kernels), B = 12 (384 rows = three groups of 128:
+    hidden-split forward and recompute backward).  Same tolerances as the regular sizes."""
+    ocfg, p, model = make("TransformerDDPM", 42, 2, 8, 1)
+    x0, g = data(B, (32, 42))
+    labels = torch.randint(1, 1001, (B,), generator=g)
+    eps = torch.randn(B, 32, 42, generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss_ref = O.diffusion_loss(x0.double(), O.make_model(leaf, ocfg), BETAS, labels.numpy(), eps.double(), "none")
+    loss_ref.mean().backward()
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    outs = []
+    for rep in range(2):
+        eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
+        torch.cuda.synchronize()
+        outs.append(eng.grads.clone())
+    assert torch.equal(outs[0], outs[1])                       # repeatable
+    m_ref = float(loss_ref.detach().mean())
+    assert abs(float(eng.loss_per_sample().mean()) - m_ref) / m_ref < 5e-3
+    gv = eng.named_views(eng.grads)
+    num = sum(float((gv[k].double().cpu() - v.grad).pow(2).sum()) for k, v in leaf.items())
+    den = sum(float(v.grad.pow(2).sum()) for v in leaf.values())
+    total = (num / den) ** 0.5
+    print(f"gradient at B={B}: whole-vector rel-L2 {total:.3e}")
+    assert total < 1e-2
+    # and the sampler's forward at the same batch size
+    s = 0.05 + 0.95 * torch.rand(B, generator=g)
+    ref = O.make_model(p, ocfg)(x0.double(), s.view(B, 1, 1).double())
+    assert rel(model(x0, s.view(B, 1, 1)), ref) < 1e-2
+
+
 def test_optimizer_step_matches_oracle():
     ocfg, p, model = make(C=42, L=2, K=1)
     B = 4
