@@ -92,6 +92,8 @@ def self_launch_if_needed(a) -> None:
         return
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("SMD_BENCH_SHARE_DEVICE") == "1" and have >= 1:
+        have = a.gpus                          # test hook: every rank on cuda:0 (see main)
     if have < a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs, this box has {have}")
     import socket
@@ -467,6 +469,12 @@ def main():
     assert world == a.gpus, (world, a.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    # test hook (tests/test_gpu_bench_config.py): SMD_BENCH_SHARE_DEVICE=1 puts every rank on cuda:0 with the gloo backend, so the
+    # multi-rank code path of this script (sharded inputs, two-stage gradient all-reduce, barriers, max over ranks) can run on a
+    # one-GPU box; the line it prints says so and is not a measurement
+    share = os.environ.get("SMD_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank}, this box has {torch.cuda.device_count()} GPUs")
     torch.cuda.set_device(local_rank)
@@ -474,7 +482,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
 
     import smd_amd.lib as lib
     from smd_amd.trainer import GradComm
@@ -546,7 +557,8 @@ def main():
             "value": head["value"], "unit": "denoising-steps/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * total / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 DenseResBlock forward GEMMs) + bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 DenseResBlock forward GEMMs) + bf16",
+            "data": "synthetic" if not share else "synthetic; TEST RUN: all ranks share cuda:0 over gloo (SMD_BENCH_SHARE_DEVICE), not a measurement",
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,

@@ -292,3 +292,28 @@ def test_every_gradient_element_is_written_without_the_memset(arch, C, B):
         bad = int((~torch.isfinite(eng.grads)).sum())
         assert bad == 0, f"{bad} gradient elements were not written (stages {stages})"
         assert torch.equal(eng.grads, ref)
+
+
+def test_bench_script_with_two_ranks_on_one_gpu():
+    """bench.py's multi-rank path end to end on a one-GPU box: `--gpus 2` launches its own two ranks, which share cuda:0 over
+    gloo (test hook SMD_BENCH_SHARE_DEVICE): sharded synthetic inputs, the two-stage gradient all-reduce of trainer.GradComm
+    between the two loss_backward stages, barriers, MAX over ranks, one JSON line from rank 0 with n_gpus = 2.  The numbers
+    are not measurements (two ranks time-slice one GPU, the collective goes through the host) and the line says so."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMD_BENCH_SHARE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1",
+                        "--no-roofline-microbench"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 512
+    assert "TEST RUN" in d["data"]
+    assert d["value"] > 0 and np.isfinite(d["final_loss"]) and 0.5 < d["final_loss"] < 3.0
+    assert d["extra_configs"] is None and d["cpu_baseline"] is None          # single-GPU extras stay out of a multi-rank line
