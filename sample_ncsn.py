@@ -38,11 +38,13 @@ def load_model(FLAGS, shape, device):
     rng = ncsn.make_key(FLAGS.sample_seed, FLAGS.rng_impl)
     rng, model_rng = ncsn.split(rng)
     model = ncsn.create_model(model_rng, shape, model_kwargs, batch_size=1, verbose=True,
-                              architecture=FLAGS.architecture, num_timesteps=FLAGS.num_sigmas, device=device, dtype=FLAGS.dtype)
+                              architecture=FLAGS.architecture, num_timesteps=FLAGS.num_sigmas, device=device, dtype=FLAGS.dtype,
+                              init=False)                       # the weights come from the checkpoint (sample_ncsn.py:331-342)
     found = (checkpoint.load_ema_params if FLAGS.sample_ema else
              lambda d, e: checkpoint.restore_checkpoint(d, e, load_optimizer_state=False)[0])(FLAGS.model_dir, model.engine)
     if not found:
         log.warning("no checkpoint under %s: sampling from freshly initialised weights", FLAGS.model_dir)
+        ncsn.init_model(model, model_rng)
     return model, rng
 
 

@@ -42,7 +42,7 @@ def _rotate(ckpt_dir: str, prefix: str, keep: int) -> None:
 
 
 def save_checkpoint(ckpt_dir: str, target, step: int, keep: int = 50, prefix: str = "checkpoint_",
-                    fmt: str = "safetensors", flax_naming: str = "shared", flax_attention_class: str = "SelfAttention") -> str:
+                    fmt: str = "safetensors", flax_naming: str = "shared", flax_attention_class: str = "MultiHeadDotProductAttention") -> str:
     """target = (optimizer, ema, early_stop) like the reference call (train_ncsn.py:397-399)."""
     optimizer, ema, early_stop = target
     eng = optimizer.engine

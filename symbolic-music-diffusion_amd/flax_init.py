@@ -16,8 +16,11 @@ flax 0.3.0 / jax 0.2.8 sources (not installable here: unpinned until tests/golde
   DenseGeneral     (attention q / k / v / out) draws its kernel with the FLATTENED shape (E, H*d) / (H*d, E), then reshapes.
 
 The auto-naming rule is the one flax_io writes and detects ("shared": one counter for all children of a module, parameter-less
-modules take a number too); it is an argument because it is the unverified part.  Host NumPy, once per model: ~5 s for the
-26.6 M parameters of the base network.
+modules take a number too; the attention module is named ``MultiHeadDotProductAttention_<n>`` because ``nn.SelfAttention`` is a
+``partial`` of that class and keeps its ``__name__`` -- see flax_io.py); both are arguments because they are the unverified
+part: a different name folds a different key into every q / k / v / out kernel, which would still be a valid lecun_normal draw
+but not the reference's.  Host NumPy, once per model: ~5 s for the 26.6 M parameters of the base network (callers that restore
+a checkpoint next skip it: ``create_model(..., init=False)``).
 """
 from __future__ import annotations
 
@@ -108,7 +111,7 @@ def lecun_normal(key: ThreefryKey, shape: Tuple[int, int]) -> np.ndarray:
 
 
 def init_params(cfg, model_rng: ThreefryKey, template: Dict[str, Tuple[int, ...]], rule: str = "shared",
-                attention_class: str = "SelfAttention") -> Dict[str, np.ndarray]:
+                attention_class: str = "MultiHeadDotProductAttention") -> Dict[str, np.ndarray]:
     """Engine-named initial parameters of ``create_model(model_rng, ...)`` (train_ncsn.py:193-203) for the network ``cfg``.
     ``template``: engine tensor name -> shape (Engine.tensor_table / the oracle's param_spec)."""
     out = {k: np.zeros(s, dtype=np.float32) for k, s in template.items()}

@@ -14,11 +14,16 @@ the flax.nn module: children are auto-named ``<ClassName>_<n>`` in call order (m
 models/shared.py:61-75), attention projections are explicitly named query / key / value / out with kernels
 (E, H, d) / (H, d, E).
 
-flax is not installable here, so both the wire format and the auto-naming rule are RESTATED FROM MEMORY (unpinned).
+flax is not installable here, so both the wire format and the auto-naming rule are RESTATED (unpinned against flax itself).
 The naming rule is the uncertain part, so the importer does not assume one: it generates the tree under every
 plausible rule (one counter shared by all child modules, with or without the parameter-less ones taking a number;
-one counter per class; attention registered as SelfAttention or MultiHeadDotProductAttention) and takes the rule
-whose key sets match the file at every level; the exporter writes the shared-counter rule unless told otherwise.
+one counter per class; attention registered as MultiHeadDotProductAttention or SelfAttention) and takes the rule
+whose key sets match the file at every level.  The exporter's default is the shared counter with the attention module
+registered as ``MultiHeadDotProductAttention_<n>``: in flax 0.3.0 ``nn.SelfAttention`` is
+``MultiHeadDotProductAttention.partial(inputs_kv=None)`` and ``Module.partial`` keeps the parent's ``__name__``; the one
+public artefact of that API we can cite from memory, the ViT checkpoints written with the same ``flax.nn`` calls
+(``LayerNorm_0 / MultiHeadDotProductAttention_1 / LayerNorm_2 / MlpBlock_3`` inside each encoder block), shows both the
+shared counter and that class name.
 """
 from __future__ import annotations
 
@@ -33,7 +38,7 @@ import numpy as np
 
 _EXT_NDARRAY, _EXT_COMPLEX, _EXT_NPSCALAR = 1, 2, 3
 NAMING_RULES = ("shared", "shared_params_only", "per_class")
-ATTENTION_CLASS_NAMES = ("SelfAttention", "MultiHeadDotProductAttention")
+ATTENTION_CLASS_NAMES = ("MultiHeadDotProductAttention", "SelfAttention")
 
 
 # ------------------------------------------------------------------ msgpack wire format (flax.serialization)
@@ -111,7 +116,7 @@ def _ln(our: str, d: int) -> Node:
     return Node("LayerNorm", None, [], {"scale": (our + ".scale", (d,), None), "bias": (our + ".bias", (d,), None)})
 
 
-def module_tree(cfg, attention_class: str = "SelfAttention") -> Node:
+def module_tree(cfg, attention_class: str = "MultiHeadDotProductAttention") -> Node:
     """Call-order tree of TransformerDDPM (models/ncsn.py:141-179) / DenseDDPM (:125-135)."""
     C, M = cfg.data_channels, cfg.mlp_dims
     E, F = getattr(cfg, "embed_channels", 128), getattr(cfg, "film_channels", 128)     # models/ncsn.py:151,173
@@ -198,7 +203,7 @@ def _set(tree, path, value):
     tree[path[-1]] = value
 
 
-def params_to_flax(named: Dict[str, np.ndarray], cfg, rule: str = "shared", attention_class: str = "SelfAttention"):
+def params_to_flax(named: Dict[str, np.ndarray], cfg, rule: str = "shared", attention_class: str = "MultiHeadDotProductAttention"):
     """Engine tensors (param_spec names / layouts) -> the nested flax parameter dict."""
     out: Dict[str, Any] = {}
     for path, our, shape, cols in _walk(module_tree(cfg, attention_class), rule):
@@ -253,7 +258,7 @@ def params_from_flax(tree: Dict[str, Any], cfg, template: Dict[str, Tuple[int, .
 
 # ------------------------------------------------------------------ whole checkpoints
 def checkpoint_state_dict(cfg, params, grad_ema, grad_sq_ema, step: int, ema_params, ema_mu: float, early_stop: Dict[str, Any],
-                          rule: str = "shared", attention_class: str = "SelfAttention") -> Dict[str, Any]:
+                          rule: str = "shared", attention_class: str = "MultiHeadDotProductAttention") -> Dict[str, Any]:
     """The state dict of (optimizer, ema, early_stop) as flax would build it; arguments are engine-named dicts."""
     f = lambda named: params_to_flax(named, cfg, rule, attention_class)
     m, v = f(grad_ema), f(grad_sq_ema)

@@ -151,22 +151,30 @@ def config_from_kwargs(architecture: str, input_shape: Sequence[int], model_kwar
                      mlp_dims=int(model_kwargs.get("mlp_dims", 2048)), num_timesteps=num_timesteps, dtype=dtype)
 
 
+def init_model(model: Model, rng: PRNGKey) -> None:
+    """The initial parameters of ``create_model(rng, ...)`` written into an existing model.  ThreefryKey: the reference's
+    ``init_by_shape(model_rng)`` draw as far as it can be restated without flax (flax_init.py: every kernel lecun_normal() of its
+    folded-in key; UNVERIFIED against flax itself until tests/golden/make_jax_goldens.py has run); engine key: NumPy lecun-normal."""
+    if isinstance(rng, ThreefryKey):
+        from . import flax_init as _fi
+        table = {name: shape for name, _off, shape in model.engine.tensor_table}
+        model.engine.load_named(_fi.init_params(model.cfg, rng, table))
+    else:
+        model.engine.init_params(rng.seed & 0x7FFFFFFF)
+
+
 def create_model(rng: PRNGKey, input_shape, model_kwargs, batch_size=32, verbose=False, *,
                  architecture: str = "TransformerDDPM", num_timesteps: int = 1000, device: str = "cuda:0",
-                 dtype: str = "bf16") -> Model:
+                 dtype: str = "bf16", init: bool = True) -> Model:
     """train_ncsn.py:193-203.  ``architecture`` replaces the FLAGS.architecture global; DenseDDPM
-    accepts-and-ignores num_heads / num_mlp_layers like the reference's kwargs."""
+    accepts-and-ignores num_heads / num_mlp_layers like the reference's kwargs.  ``init=False`` leaves the
+    parameters zero for a caller that restores a checkpoint next (the threefry initialiser costs ~5 s of host time) and
+    calls ``init_model`` itself when there is none."""
     del batch_size
     cfg = config_from_kwargs(architecture, input_shape, model_kwargs, num_timesteps, dtype)
-    if isinstance(rng, ThreefryKey):
-        # the reference's own initial weights: init_by_shape(model_rng) of the flax.nn module tree, every kernel
-        # lecun_normal() of its folded-in key (flax_init.py; with --rng_impl=threefry the step-0 state is the reference's)
-        from . import flax_init as _fi
-        model = Model(cfg, device, seed=None)
-        table = {name: shape for name, _off, shape in model.engine.tensor_table}
-        model.engine.load_named(_fi.init_params(cfg, rng, table))
-    else:
-        model = Model(cfg, device, seed=rng.seed & 0x7FFFFFFF)
+    model = Model(cfg, device, seed=None)
+    if init:
+        init_model(model, rng)
     if verbose:
         from .train_utils import report_model
         report_model(model)

@@ -25,7 +25,7 @@ def test_primitives_match_the_oracle_restatement_bit_for_bit():
         for d in (0, 1, 7, 0xFFFFFFFF, 0x9E3779B9):
             f = FI.fold_in(k, d)
             assert (np.uint32(f.k0), np.uint32(f.k1)) == tuple(O.jax_fold_in(okey(k), d))
-        for s in ("kernel", "Dense_1", "SelfAttention_3", "query"):
+        for s in ("kernel", "Dense_1", "MultiHeadDotProductAttention_3", "query"):
             f = FI.fold_in_str(k, s)
             assert (np.uint32(f.k0), np.uint32(f.k1)) == tuple(O.flax_fold_in_str(okey(k), s))
             want = int.from_bytes(hashlib.sha1(s.encode()).digest()[:4], "big")

@@ -83,10 +83,10 @@ def test_parameter_tree_names_and_layouts():
     named = {k: rng.standard_normal(s).astype(np.float32) for k, s in spec.items()}
     t = FI.params_to_flax(named, CFG)
     # call order of models/ncsn.py:141-179 under one shared child counter (parameter-less modules take a number too)
-    assert list(t) == ["Dense_1", "LayerNorm_2", "SelfAttention_3", "LayerNorm_4", "Dense_5", "Dense_6", "LayerNorm_7",
-                       "SelfAttention_8", "LayerNorm_9", "Dense_10", "Dense_11", "LayerNorm_12", "Dense_13", "DenseFiLM_14",
+    assert list(t) == ["Dense_1", "LayerNorm_2", "MultiHeadDotProductAttention_3", "LayerNorm_4", "Dense_5", "Dense_6", "LayerNorm_7",
+                       "MultiHeadDotProductAttention_8", "LayerNorm_9", "Dense_10", "Dense_11", "LayerNorm_12", "Dense_13", "DenseFiLM_14",
                        "DenseResBlock_15", "DenseFiLM_16", "DenseResBlock_17", "LayerNorm_18", "Dense_19"]
-    att = t["SelfAttention_3"]
+    att = t["MultiHeadDotProductAttention_3"]
     assert list(att) == ["query", "key", "value", "out"]
     assert att["query"]["kernel"].shape == (128, 8, 16) and att["key"]["bias"].shape == (8, 16)
     assert att["out"]["kernel"].shape == (8, 16, 128) and att["out"]["bias"].shape == (128,)

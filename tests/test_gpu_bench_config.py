@@ -29,7 +29,7 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def build(name, seed=0):
+def build(name, seed=0, dtype="bf16"):
     import smd_amd.ncsn as N
     from smd_amd.engine import NetConfig
     kw = CONFIGS[name]
@@ -42,7 +42,7 @@ def build(name, seed=0):
         elif k.endswith(".scale"):
             p[k] = 1 + 0.1 * torch.randn(p[k].shape, generator=g)
     cfg = NetConfig(architecture="TransformerDDPM", data_channels=C, seq_len=32, num_layers=kw["L"], num_heads=kw["H"],
-                    num_mlp_layers=kw["K"], num_timesteps=1000)
+                    num_mlp_layers=kw["K"], num_timesteps=1000, dtype=dtype)
     model = N.Model(cfg, "cuda:0", seed=None)
     model.engine.load_named(p)
     return ocfg, p, model
@@ -119,12 +119,14 @@ def test_train_step_parity_at_bench_size(name):
     assert not torch.equal(before, eng.params)
 
 
-@pytest.mark.parametrize("name", ["base", "large"])
-def test_reverse_steps_through_the_captured_graph(name):
+@pytest.mark.parametrize("name,dtype", [("base", "bf16"), ("large", "bf16"), ("base", "fp8"), ("large", "fp8")])
+def test_reverse_steps_through_the_captured_graph(name, dtype):
     """Three reverse iterations t = 999, 998, 997 with explicit z draws, replayed from ONE captured hipGraph (the
-    path bench.py and sample_ncsn.py time), against the oracle rollout (utils/ebm_utils.py:327-394)."""
+    path bench.py and sample_ncsn.py time), against the oracle rollout (utils/ebm_utils.py:327-394).  fp8: the e4m3
+    DenseResBlock GEMMs inside the captured step (`extra_configs.base_fp8 / large_fp8` of the bench line); the state
+    tolerance stays 1e-2, the eps_hat-norm metric gets the fp8 forward tolerance of SURVEY 8c (5e-2)."""
     import smd_amd.lib as lib
-    ocfg, p, model = build(name)
+    ocfg, p, model = build(name, dtype=dtype)
     g = torch.Generator().manual_seed(4321)
     init = torch.randn(B, 32, C, generator=g)
     zs = {t: torch.randn(B, 32, C, generator=g) for t in (999, 998, 997)}
@@ -167,16 +169,19 @@ def test_reverse_steps_through_the_captured_graph(name):
     per_t = (metrics_partial.sum(dim=1) / float(B * C)).cpu()           # rows indexed by t: (grad, step, noise)
     got = torch.stack([per_t[[999, 998, 997], 0], per_t[[999, 998, 997], 1], per_t[[999, 998, 997], 2]])
     want = torch.stack([mref[0, :3, 0], mref[1, :3, 0], mref[3, :3, 0]])
-    print(f"[{name}] 3 graph-replayed reverse steps: state rel {e:.3e}; metrics rel {rel(got, want):.3e}")
+    print(f"[{name} {dtype}] 3 graph-replayed reverse steps: state rel {e:.3e}; metrics rel {rel(got, want):.3e}")
     assert e < 1e-2
-    assert rel(got, want) < 1e-2
+    assert rel(got, want) < (1e-2 if dtype == "bf16" else 5e-2)
 
 
-def test_train_step_bitwise_repeatable():
+@pytest.mark.parametrize("name,dtype,repeats", [("base", "bf16", 500), ("large", "bf16", 100), ("base", "fp8", 100)])
+def test_train_step_bitwise_repeatable(name, dtype, repeats):
     """same inputs twice => bitwise equal, for the whole training step with the shipped defaults
-    (two HIP streams inside the engine).  20 x loss_backward on identical inputs, then two identical optimiser
-    trajectories from the same state."""
-    _, p, model = build("base")
+    (two HIP streams inside the engine).  `repeats` x loss_backward on identical inputs (500 at the headline configuration:
+    the event this gates -- a LayerNorm backward disturbed by a co-resident weight-gradient workgroup, DESIGN section 6 --
+    showed up in 1-2 % of the steps of the worst default build), then two identical optimiser trajectories from the same
+    state.  Every configuration the bench line times is covered: base, large, and the e4m3 path."""
+    _, p, model = build(name, dtype=dtype)
     x0, labels, eps, _ = draws()
     eng = model.train_engine(ema=False)
     eng.set_schedule(BETAS, with_sampler=False)
@@ -184,7 +189,7 @@ def test_train_step_bitwise_repeatable():
     xd, ld, ed = x0.cuda(), labels.int().cuda(), eps.cuda()
     ref_g = ref_l = ref_p = None
     bad = []
-    for it in range(20):
+    for it in range(repeats):
         eng.loss_backward(xd, ld, ed, stage=0)
         torch.cuda.synchronize()
         if ref_g is None:
@@ -193,7 +198,7 @@ def test_train_step_bitwise_repeatable():
         if not (torch.equal(eng.grads, ref_g) and torch.equal(eng.loss_per_sample(), ref_l) and torch.equal(eng.last_pred(), ref_p)):
             gv, rv = eng.named_views(eng.grads), eng.named_views(ref_g)
             bad.append((it, [k for k in gv if not torch.equal(gv[k], rv[k])][:4]))
-    assert not bad, f"loss_backward is not bitwise repeatable: {bad[:3]}"
+    assert not bad, f"loss_backward is not bitwise repeatable: {len(bad)} of {repeats - 1} repeats differ, first {bad[:3]}"
 
     def trajectory():
         eng.params.copy_(start)

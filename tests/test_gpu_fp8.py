@@ -116,13 +116,18 @@ def test_layernorm_fwd_e4m3(L, dev):
     assert ((((s.cpu().to(torch.int64) & 0xFF) - 127) - e_ref).abs() <= 1).all()      # bf16-free fp32 row maximum: same binade
 
 
-@pytest.mark.parametrize("B,L_,H,K_", [(8, 6, 8, 2), (256, 6, 8, 2), (16, 8, 16, 3)])
-def test_fp8_forward_and_train_step_parity(B, L_, H, K_):
-    """--dtype=fp8 engine vs the fp32 oracle: eps_hat <= 5e-2; the training step (e4m3 forward GEMMs, bf16
-    backward on the bf16 copies of the same activations) stays close to the oracle's loss and gradient."""
+GRAD_TOL = 5e-2      # whole-gradient rel-L2 in fp8 mode: the SURVEY 8c eps_hat tolerance carried over to the gradient
+
+
+@pytest.mark.parametrize("B,L_,H,K_,C", [(8, 6, 8, 2, 512), (256, 6, 8, 2, 512), (16, 8, 16, 3, 512), (256, 8, 16, 3, 512),
+                                         (8, 6, 8, 2, 146), (256, 6, 8, 2, 146)])
+def test_fp8_forward_and_train_step_parity(B, L_, H, K_, C):
+    """--dtype=fp8 engine vs the fp32 oracle: eps_hat <= 5e-2; the training step (e4m3 forward and dgrad GEMMs of
+    the DenseResBlocks, bf16 weight gradients on the bf16 copies of the same activations) stays inside GRAD_TOL of the oracle's
+    gradient and 2e-2 of its loss.  Cases: the B = 256 steps `extra_configs.base_fp8 / large_fp8` of the bench line time, and
+    the multitrack slice C = 146 that BASELINE config 5 names (configs/ddpm-multi-32seq-512.cfg: ragged in_proj / out_proj)."""
     import smd_amd.ncsn as N
     from smd_amd.engine import NetConfig
-    C = 512
     ocfg = O.NetConfig(data_channels=C, num_layers=L_, num_heads=H, num_mlp_layers=K_)
     p = O.init_params(ocfg, 0, torch.float32)
     g = torch.Generator().manual_seed(5)
@@ -145,11 +150,9 @@ def test_fp8_forward_and_train_step_parity(B, L_, H, K_):
                            num_mlp_layers=K_, num_timesteps=1000), "cuda:0", seed=None)
     bf.engine.load_named(p)
     e_bf = rel(bf(x, s.view(B, 1, 1)), ref)
-    print(f"fp8 forward B={B} L={L_} H={H} K={K_}: eps_hat rel {e:.3e} (bf16 engine: {e_bf:.3e})")
+    print(f"fp8 forward B={B} L={L_} H={H} K={K_} C={C}: eps_hat rel {e:.3e} (bf16 engine: {e_bf:.3e})")
     assert e < 5e-2
     assert e > e_bf                                         # the e4m3 path really ran (it cannot be as exact as bf16)
-    if B > 64:
-        return
     labels = torch.randint(1, 1001, (B,), generator=g)
     eps = torch.randn(B, 32, C, generator=g)
     leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
@@ -161,21 +164,31 @@ def test_fp8_forward_and_train_step_parity(B, L_, H, K_):
     eng.loss_backward(x.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
     torch.cuda.synchronize()
     m_eng, m_ref = float(eng.loss_per_sample().mean()), float(loss_ref.detach().mean())
-    gv = eng.named_views(eng.grads)
-    num = sum(float((gv[k].double().cpu() - v.grad.double()).pow(2).sum()) for k, v in leaf.items())
-    den = sum(float(v.grad.double().pow(2).sum()) for v in leaf.values())
-    e_g = (num / den) ** 0.5
+    e_l = rel(eng.loss_per_sample(), loss_ref)
+
+    def grad_err():
+        gv = eng.named_views(eng.grads)
+        num = den = 0.0
+        worst, worst_name = 0.0, ""
+        for k, v in leaf.items():
+            d2, n2 = float((gv[k].double().cpu() - v.grad.double()).pow(2).sum()), float(v.grad.double().pow(2).sum())
+            num, den = num + d2, den + n2
+            if n2 > 0 and (d2 / n2) ** 0.5 > worst:
+                worst, worst_name = (d2 / n2) ** 0.5, k
+        return (num / den) ** 0.5, worst, worst_name
+
+    e_g, w_g, w_name = grad_err()
     # the same step with the DenseResBlock dgrad GEMMs back on bf16 operands (option fp8_dgrad = 0): the e4m3 dgrads are the
     # default in fp8 mode (4 of the step's 14 large GEMMs more on the 5 PF path) and must stay inside the same tolerance
     g8 = eng.grads.clone()
     eng.set_option("fp8_dgrad", 0)
     eng.loss_backward(x.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
     torch.cuda.synchronize()
-    gv = eng.named_views(eng.grads)
-    num_b = sum(float((gv[k].double().cpu() - v.grad.double()).pow(2).sum()) for k, v in leaf.items())
-    e_gb = (num_b / den) ** 0.5
+    e_gb, _, _ = grad_err()
     eng.set_option("fp8_dgrad", 1)
-    print(f"fp8 train step B={B}: loss {m_eng:.6f} vs {m_ref:.6f}; gradient whole-vector rel {e_g:.3e} (bf16 dgrads: {e_gb:.3e})")
+    print(f"fp8 train step B={B} C={C}: loss {m_eng:.6f} vs {m_ref:.6f} (per-sample rel {e_l:.3e}); gradient whole-vector rel "
+          f"{e_g:.3e}, worst tensor {w_name} {w_g:.3e} (bf16 dgrads: {e_gb:.3e})")
     assert abs(m_eng - m_ref) / m_ref < 2e-2
-    assert e_g < 8e-2 and e_gb < 8e-2
+    assert e_g < GRAD_TOL and e_gb < GRAD_TOL
+    assert w_g < 0.25
     assert not torch.equal(g8, eng.grads)                   # the e4m3 dgrad path really ran
