@@ -66,7 +66,7 @@ def parse(argv=None):
                     help="noise streams: in-kernel Philox (default) or jax.random-compatible threefry2x32 draws")
     ap.add_argument("--side-wgrad", type=int, default=1, help="wgrad GEMMs on the engine's side stream (0: single stream)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
-                    help="fp8: OCP e4m3 operands with per-row E8M0 scales for the DenseResBlock forward GEMMs (BASELINE config 5)")
+                    help="fp8: OCP e4m3 operands with per-row E8M0 scales for the DenseResBlock forward and dgrad GEMMs (BASELINE config 5)")
     ap.add_argument("--dp-buckets", type=int, default=1, help="N > 1 GPUs: chunks per gradient all-reduce stage (GradComm)")
     ap.add_argument("--dp-payload", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1 GPUs: wire format of the gradient all-reduce (bf16 halves the xGMI bytes; off by default)")
@@ -557,7 +557,7 @@ def main():
             "value": head["value"], "unit": "denoising-steps/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1e3 * total / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 DenseResBlock forward GEMMs) + bf16",
+            "vs_baseline": None, "dtype": "bf16" if a.dtype == "bf16" else "fp8 (e4m3 DenseResBlock forward + dgrad GEMMs) + bf16",
             "data": "synthetic" if not share else "synthetic; TEST RUN: all ranks share cuda:0 over gloo (SMD_BENCH_SHARE_DEVICE), not a measurement",
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",

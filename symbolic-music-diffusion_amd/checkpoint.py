@@ -69,7 +69,8 @@ def save_checkpoint(ckpt_dir: str, target, step: int, keep: int = 50, prefix: st
     tensors.update(_named(eng, ema_flat, "ema/params"))
     meta = {"early_stop": json.dumps(early_stop.state_dict() if early_stop else {}),
             "ema_mu": str(getattr(ema, "mu", 0.0)), "format": "smd_amd-1",
-            "trunk_dtype": str(getattr(eng, "trunk_dtype", "bf16")), "gemm_dtype": str(eng.cfg.dtype)}
+            "trunk_dtype": str(getattr(eng, "trunk_dtype", "bf16")), "gemm_dtype": str(eng.cfg.dtype),
+            "fp8_dgrad": str(int(getattr(eng, "fp8_dgrad", 1)) if eng.cfg.dtype == "fp8" else 0)}
     path = os.path.join(ckpt_dir, f"{prefix}{step}")
     save_file(tensors, path + ".tmp", metadata=meta)
     os.replace(path + ".tmp", path)

@@ -1295,6 +1295,8 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
     if (kh == 0) { stt[(w * S_TOK + l31) * 2] = ps; stt[(w * S_TOK + l31) * 2 + 1] = ps2; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the statistics only: __syncthreads() would also wait for the h_out stores
     __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);                       // s_barrier is IntrNoMem: keep the stt[] reads below it
+    asm volatile("" ::: "memory");
     AT_TS(14)
     float s = 0.f, s2 = 0.f;
 #pragma unroll

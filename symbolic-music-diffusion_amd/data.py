@@ -101,11 +101,15 @@ class ArrayLatents:
         self.array = torch.from_numpy(array)
         self.device = device
         self.host_resident = bool(shuffle) and world_size > 1 and device is not None
+        self._pinned_shard = None
         if self.host_resident:
+            # the whole split stays in PAGEABLE host memory on every rank; only this rank's per-epoch shard (per rows) is
+            # staged through one pinned buffer, so pinned memory does not grow with the world size and the H2D copy of the
+            # gathered shard is a real asynchronous DMA (a gather result is pageable: its copy would be staged and blocking)
             try:
-                self.array = self.array.pin_memory()
+                self._pinned_shard = torch.empty((per, *self.array.shape[1:]), dtype=torch.float32).pin_memory()
             except Exception:            # no accelerator runtime (CPU-only tests): pageable memory works the same
-                pass
+                self._pinned_shard = None
         elif device is not None:
             self.array = self.array.to(device)   # resident in HBM: no per-step H2D copy
         self.batch_size = batch_size
@@ -135,7 +139,12 @@ class ArrayLatents:
         idx = self.epoch_order(self.epoch)
         self.epoch += 1
         if self.host_resident:           # this rank's share of the epoch: one gather on the host, one H2D copy
-            shard = self.array.index_select(0, idx).to(self.device, non_blocking=True)
+            if self._pinned_shard is not None:
+                torch.index_select(self.array, 0, idx, out=self._pinned_shard)
+                shard = self._pinned_shard.to(self.device, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()     # the buffer is rewritten at the next epoch boundary
+            else:
+                shard = self.array.index_select(0, idx).to(self.device)
             for i in range(self.examples):
                 yield shard[i * self.batch_size:(i + 1) * self.batch_size]
             return

@@ -230,7 +230,10 @@ SAMPLE_FLAGS: List[FlagDef] = [
 # engine-only additions (no collision with the reference surface)
 ENGINE_FLAGS: List[FlagDef] = [
     _D("dtype", "enum", "bf16", "GEMM operand precision of the HIP path: bf16, or fp8 = OCP e4m3 operands with per-row "
-       "E8M0 scales for the DenseResBlock forward GEMMs (BASELINE config 5), bf16 elsewhere.", ("bf16", "fp8")),
+       "E8M0 scales for the DenseResBlock forward GEMMs and (training, --fp8_dgrad) their input-gradient GEMMs "
+       "(BASELINE config 5); weight gradients and everything 128-wide stay bf16.", ("bf16", "fp8")),
+    _D("fp8_dgrad", "bool", True, "--dtype=fp8 training: the four DenseResBlock dgrad GEMMs (dX = dY W^T) on e4m3 operands too "
+       "(gradient parity 1.6e-2 vs 1.4e-2 with bf16 dgrads; recorded in the checkpoint metadata).  --nofp8_dgrad: bf16 dgrads."),
     _D("trunk_dtype", "enum", "bf16", "Storage type of the 2048-wide residual trunk between the DenseResBlocks DURING TRAINING: "
        "bf16 (default: +2 % train throughput; eps_hat parity 5.7e-3 -> 6.3e-3, loss curves indistinguishable over 400 steps, "
        "profiles/r3_trunk_dtype_curves.txt) or fp32 as the reference keeps it.  Logged at start-up and recorded in the "

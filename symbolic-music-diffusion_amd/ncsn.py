@@ -437,6 +437,12 @@ def annealed_langevin_dynamics(rng: PRNGKey, model: Model, sigmas, init, epsilon
             k = si * T + i
             io = _langevin_io(x, grad, alpha, np.sqrt(np.float32(2) * alpha), rng, k, sample_offset, metrics[k],
                               collection[slot] if 0 < slot < n_coll else None)
+            if jax_mode:
+                # explicit infill draws next to the reference's own step-noise stream (noises is None): the update draws
+                # jax.random.normal of this iteration's key itself instead of falling back to Philox
+                io.use_threefry, io.tf_n_total = 1, n_glob
+                io.tf_noise_key[0], io.tf_noise_key[1] = int(step_keys[k][0]), int(step_keys[k][1])
+                io.tf_infill_key[0], io.tf_infill_key[1] = int(infill_keys[k][0]), int(infill_keys[k][1])
             if zbuf is not None:
                 zbuf.copy_(torch.as_tensor(noises(si, i)).to(dev, torch.float32))
                 io.z_in = zbuf.data_ptr()

@@ -181,6 +181,13 @@ def test_annealed_langevin_reference_streams_and_sample_api():
     gs, gc, gm = N.annealed_langevin_dynamics(tk, model, sig, init, 2e-5, T, True, True, inf_s, inf_m)
     print(f"ald threefry + infill: state rel {rel(gs, rs):.3e} collection rel {rel(gc, rc):.3e} metrics rel {rel(gm, rm):.3e}")
     assert rel(gs, rs) < 1e-2 and rel(gc, rc) < 1e-2 and rel(gm, rm) < 1e-2
+    # mixed arguments: a ThreefryKey with EXPLICIT infill draws and no explicit step noise goes through the eager
+    # loop; the step noise must still be the reference's threefry stream (not Philox of key.seed).  With the infill draws
+    # set to what the infill keys would have produced, the run equals the all-threefry one.
+    gm_s, gm_c, _ = N.annealed_langevin_dynamics(tk, model, sig, init, 2e-5, T, True, True, inf_s, inf_m,
+                                                 infill_noises=lambda si, i: draw(fk[si * T + i]).float())
+    print(f"ald threefry step noise + explicit infill draws vs all-threefry: state rel {rel(gm_s, gs):.3e}")
+    assert rel(gm_s, gs) < 1e-4 and rel(gm_c, gc) < 1e-4
     # a 1-row shard of the same global draw reproduces row 1 (the key window, not the shard, indexes the stream)
     g1, _, _ = N.annealed_langevin_dynamics(tk, model, sig, init[1:], 2e-5, T, True, True, inf_s[1:], inf_m[1:],
                                             sample_offset=1, global_num_samples=2)

@@ -80,8 +80,11 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
     optimizer = create_optimizer(model, FLAGS.learning_rate, ema=FLAGS.ema)       # :332
     optimizer.engine.set_option("trunk_bf16", 2 if FLAGS.trunk_dtype == "bf16" else 1)
     optimizer.engine.trunk_dtype = FLAGS.trunk_dtype                               # recorded in the checkpoint metadata
+    optimizer.engine.fp8_dgrad = int(bool(FLAGS.fp8_dgrad))                        # likewise (only meaningful with --dtype=fp8)
+    optimizer.engine.set_option("fp8_dgrad", optimizer.engine.fp8_dgrad)
     if rank == 0:
-        log.info("training trunk dtype: %s (GEMM operands: %s)", FLAGS.trunk_dtype, FLAGS.dtype)
+        log.info("training trunk dtype: %s (GEMM operands: %s%s)", FLAGS.trunk_dtype, FLAGS.dtype,
+                 "" if FLAGS.dtype != "fp8" else (", e4m3 dgrads" if FLAGS.fp8_dgrad else ", bf16 dgrads"))
     comm = GradComm() if world > 1 else None
     if comm is not None:
         comm.broadcast_params(model.params)
