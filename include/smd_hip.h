@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 3   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots */
+#define SMD_ABI_VERSION 4   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots; 4: one-sweep optimiser, "opt_overlap", smd_engine_join_update */
 
 typedef uint16_t smd_bf16;
 typedef struct smd_engine smd_engine;
@@ -76,7 +76,16 @@ int smd_engine_padded_channels(const smd_engine* e);
  *   "label_min" 1/0      Philox labels in [1, T] (continuous_noise) or [0, T);  "loss_kind" 0/1  DDPM / score matching
  *   "grad_memset" 2      0 never / 1 always / 2 only with the tr_path = 0 fallback: zero the gradient buffer before a step
  *                        (every gradient element is written, not accumulated, by the default kernels)
- *   "nt256_min_tiles" 0  > 0: Dense layers take the 256x256 GEMM from this many output tiles up (default rule: 192) */
+ *   "nt256_min_tiles" 0  > 0: Dense layers take the 256x256 GEMM from this many output tiles up (default rule: 192)
+ *   "fp8_dgrad" 1        fp8 mode, training: the DenseResBlock dgrad GEMMs on e4m3 operands too
+ *   "opt_overlap" 0      smd_engine_optimizer_step placement (any time).  Bit 0: the update of the output-stage slice (parameters
+ *                        >= smd_engine_head_param_offset, ~75 % of the bytes) runs on the side stream and is NOT complete in
+ *                        stream order when the call returns: the next smd_engine_loss_backward of the same handle waits for it
+ *                        right before its first output-stage kernel; any other reader of params / m / v / ema / wpack (another
+ *                        handle on the same buffers, a host copy) calls smd_engine_join_update(handle, its stream) first.
+ *                        Bit 1: smd_engine_loss_backward(stage 0) reduces that slice's gradient-norm partials on the side
+ *                        stream under the encoder backward; the caller must not change the gradient before the optimiser step
+ *                        (leave it off around an all-reduce).  The Python host sets 3 (1 with a communicator). */
 int smd_engine_set_option(smd_engine* e, const char* key, int value);
 
 int smd_engine_bind_params(smd_engine* e, float* params, smd_bf16* wpack);
@@ -127,6 +136,8 @@ typedef struct smd_train_hyper {
   float grad_scale;        /* multiplies the gradients first (1/world_size after a SUM all-reduce) */
 } smd_train_hyper;
 int smd_engine_optimizer_step(smd_engine* e, const smd_train_hyper* h, void* stream);
+/* Makes `stream` wait for an output-stage update deferred by "opt_overlap" bit 0 (no-op when none is pending). */
+int smd_engine_join_update(smd_engine* e, void* stream);
 
 /* diffusion_dynamics (utils/ebm_utils.py:280-405), one sample_with_beta iteration per call */
 typedef struct smd_sample_io {

@@ -98,6 +98,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "mlp_hs") { e->impl.mlp_hs = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8_dgrad") { e->impl.fp8_dgrad = value ? 1 : 0; return 0; }
+  if (std::string(key) == "opt_overlap") { e->impl.opt_overlap = value & 3; return 0; }
   if (std::string(key) == "w8_dirty") { e->impl.mark_w8_dirty(); return 0; }   // the bf16 operand pack changed under another handle
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;
@@ -144,6 +145,7 @@ int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes) {
 const float* smd_engine_loss_per_sample(const smd_engine* e) { return e ? e->impl.loss_per_sample() : nullptr; }
 const float* smd_engine_pred(const smd_engine* e) { return e ? e->impl.pred() : nullptr; }
 
+int smd_engine_join_update(smd_engine* e, void* stream) { NEED(e); return e->impl.join_update(S(stream)); }
 int smd_engine_optimizer_step(smd_engine* e, const smd_train_hyper* h, void* stream) {
   NEED(e);
   SMD_ARG_CHECK(h, "optimizer_step: null hyper-parameters");

@@ -98,6 +98,17 @@ class SmdEngine {
   int loss_backward(const float* x0, const int* labels, const float* eps_in, uint32_t seed_lo, uint32_t seed_hi,
                     uint32_t sample_offset, float inv_global_count, int stage, hipStream_t st);
   int optimizer_step(const TrainHyper& h, hipStream_t st);
+  // Optimiser placement (optimizer_step is ONE sweep -- clip + Adam + EMA + bf16 re-cast -- in every mode):
+  //   bit 0  the update of the OUTPUT-STAGE slice (parameters >= head_param_offset: ~75 % of the bytes, not needed before the
+  //          `up` projection of the next forward pass) runs on the engine's side stream behind the stem slice's norm; the next
+  //          run_network() of THIS handle waits for it right before the first output-stage kernel, every other reader of the
+  //          parameters / Adam state / operand pack (another handle, the host, a checkpoint) must call join_update() first;
+  //   bit 1  loss_backward(stage 0) reduces the output-stage slice's gradient-norm partials on the side stream as soon as that
+  //          slice is final (under the encoder backward) instead of in optimizer_step -- valid only when nothing changes the
+  //          gradient between the two calls (no all-reduce: the data-parallel path leaves this bit off).
+  // 0 (default): everything on the caller's stream, complete in stream order when optimizer_step returns.
+  int opt_overlap = 0;
+  int join_update(hipStream_t st);      // make `st` wait for a deferred output-stage update (no-op when none is pending)
   int prepare_sampler(hipStream_t st);                       // FiLM tables for every timestep
   int sample_step(const SampleStepIO& io, hipStream_t st);   // eps-net forward + fused reverse step
   int init_state(float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset, hipStream_t st);
@@ -213,6 +224,12 @@ class SmdEngine {
   bool w8_dirty_ = true;                       // the e4m3 weight copies are older than the bf16 operand pack
   bool hs_train_ = false;                      // the forward pass of this step used the hidden-split MLP dataflow
   hipEvent_t take_event();
+  OptTable opt_stem_, opt_head_;               // tile tables of the fused optimiser sweep (parameters < / >= head_off_)
+  void build_opt_tables();
+  bool opt_fused_ok_ = true;
+  bool head_norm_ready_ = false;               // slots [0, 512) of norm_partial hold this step's output-stage partials (side stream)
+  bool head_pending_ = false;                  // an output-stage update is in flight on the side stream
+  hipEvent_t head_done_ev_ = nullptr;          // recorded behind it (owned; not from the recycled pool)
 
   struct Work {
     // inputs / outputs of the network
@@ -264,7 +281,8 @@ class SmdEngine {
     float* tn_slab = nullptr;             // split-K partial tiles of the wgrad kernel (main stream)
     float* tn_slab_side = nullptr;        // the same for wgrads issued on the side stream
     size_t tn_slab_elems = 0;
-    float* norm_partial = nullptr;        // [1024]
+    float* norm_partial = nullptr;        // [1024]: slots [0, 512) output-stage slice, [512, 1024) stem slice
+    float* opt_consts = nullptr;          // [8]: clip multiplier, lr, 1/(1-b1^t), 1/(1-b2^t) of the current update
     bf16_t* zero_page = nullptr;          // [128]
     unsigned* step_arrive = nullptr;      // [64] arrival counter of the fused reverse step
     float* mlp_part = nullptr;            // [4][R][E] partial tiles of the hidden-split MLP kernels

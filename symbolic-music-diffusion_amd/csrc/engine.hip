@@ -34,6 +34,8 @@ int launch_pos_encoding(float* pe, int S, int channels, hipStream_t st);
 // ------------------------------------------------------------------ layout
 SmdEngine::SmdEngine(const SmdModelDesc& d) : d_(d) { build_layout(); }
 SmdEngine::~SmdEngine() {
+  if (side_) (void)hipStreamSynchronize(side_);        // a deferred update may still be reading the caller's buffers
+  if (head_done_ev_) (void)hipEventDestroy(head_done_ev_);
   for (hipEvent_t e : events_) (void)hipEventDestroy(e);
   if (side_) (void)hipStreamDestroy(side_);
 }
@@ -216,6 +218,41 @@ void SmdEngine::build_layout() {
   if (d_.arch == 0) all_dense_.push_back(&up_);
   for (auto& b : blk_) { all_dense_.push_back(&b.f1); all_dense_.push_back(&b.f2); all_dense_.push_back(&b.ss); all_dense_.push_back(&b.r1); all_dense_.push_back(&b.r2); }
   all_dense_.push_back(&out_proj_);
+  build_opt_tables();
+}
+
+// Work list of the fused optimiser sweep: every Dense kernel as 64 x 64 tiles, everything between two kernels (biases,
+// LayerNorm scale / bias) as flat runs of 1024 elements; one table per slice so the two slices can go to different streams.
+void SmdEngine::build_opt_tables() {
+  for (int part = 0; part < 2; ++part) {
+    OptTable& t = part == 0 ? opt_stem_ : opt_head_;
+    t = OptTable();
+    const int64_t lo = part == 0 ? 0 : head_off_, hi = part == 0 ? head_off_ : n_params_;
+    uint32_t blk = 0;
+    std::vector<std::pair<int64_t, int64_t>> dense_ranges;
+    for (const DenseP* p : all_dense_) {
+      if (p->w_off < lo || p->w_off >= hi) continue;
+      if (t.n_dense == SMD_OPT_DENSE_MAX || t.n_flat + 2 >= SMD_OPT_FLAT_MAX) { opt_fused_ok_ = false; return; }   // very deep DenseDDPM: three-pass fallback
+      OptDense& e = t.d[t.n_dense++];
+      e.w_off = (uint32_t)p->w_off; e.K = (uint32_t)p->K; e.N = (uint32_t)p->N;
+      e.W_off = (uint32_t)p->W_off; e.ldw = (uint32_t)p->Np; e.Wt_off = (uint32_t)p->Wt_off; e.ldwt = (uint32_t)p->Kp;
+      e.blk_start = blk;
+      blk += (uint32_t)(((p->K + 63) / 64) * ((p->N + 63) / 64));
+      dense_ranges.emplace_back(p->w_off, p->w_off + (int64_t)p->K * p->N);
+    }
+    t.flat_blk0 = blk;
+    int64_t cur = lo;
+    auto add_flat = [&](int64_t a, int64_t b) {
+      if (b <= a) return;
+      if (t.n_flat == SMD_OPT_FLAT_MAX) { opt_fused_ok_ = false; return; }
+      OptFlat& f = t.f[t.n_flat++];
+      f.off = (uint32_t)a; f.len = (uint32_t)(b - a); f.blk_start = blk;
+      blk += (uint32_t)((b - a + 1023) / 1024);
+    };
+    for (auto& r : dense_ranges) { add_flat(cur, r.first); cur = r.second; }      // all_dense_ is in parameter order
+    add_flat(cur, hi);
+    t.total_blocks = blk;
+  }
 }
 
 // ------------------------------------------------------------------ workspace planner
@@ -335,6 +372,7 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     t.tn_slab = c.take<float>(t.tn_slab_elems);
     t.tn_slab_side = c.take<float>(t.tn_slab_elems);
     t.norm_partial = c.take<float>(1024);
+    t.opt_consts = c.take<float>(8);
     const size_t Mp = (R + 63) / 64 * 64;
     t.tn_scratch_elems = tr_path ? 0 : (size_t)2 * (2 * M) * Mp;
     t.tn_scratch = t.tn_scratch_elems ? c.take<bf16_t>(t.tn_scratch_elems) : nullptr;
@@ -360,6 +398,7 @@ int SmdEngine::bind_workspace(void* ws, int64_t bytes, int batch, int training, 
   SMD_ARG_CHECK(ws && batch > 0, "bind_workspace: null workspace or batch=%d", batch);
   const int64_t need = plan(nullptr, batch, training, nullptr);
   SMD_ARG_CHECK(bytes >= need, "bind_workspace: %lld bytes given, %lld needed", (long long)bytes, (long long)need);
+  RC(join_update(st));                     // a deferred update reads the optimiser constants of the OLD workspace
   plan(ws, batch, training, &W);
   batch_ = batch; training_ = training;
   w8_dirty_ = true;
@@ -375,8 +414,17 @@ int SmdEngine::bind_schedule(const float* coef, const float* sqrt_ap, const floa
   return 0;
 }
 
+int SmdEngine::join_update(hipStream_t st) {
+  if (!head_pending_) return 0;
+  hipError_t e = hipStreamWaitEvent(st, head_done_ev_, 0);
+  if (e != hipSuccess) { smd_set_error("join_update: %s", hipGetErrorString(e)); return (int)e; }
+  head_pending_ = false;
+  return 0;
+}
+
 int SmdEngine::refresh_weights(hipStream_t st) {
   SMD_ARG_CHECK(params_ && wpack_, "refresh_weights: parameters not bound");
+  RC(join_update(st));
   w8_dirty_ = true;
   size_t i = 0;
   while (i < all_dense_.size()) {                 // one launch per <= SMD_RECAST_MAX weights (normally one)
@@ -517,6 +565,7 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
           RC(dense_fwd(p.fc2, W.u[i], M, R, ep, st)); }
       }
     }
+    RC(join_update(st));     // a deferred output-stage update of the previous step (opt_overlap): everything below reads its parameters
     {  // models/ncsn.py:170-171
       if (parts_pending) {
         RC(launch_ln128_parts(W.mlp_part, (size_t)R * E, R, P(ln_f_.g_off), P(ln_f_.b_off), tr ? W.h_last : nullptr, W.af, st));
@@ -533,6 +582,7 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
     GemmEpilogue ep;
     if (tb) { ep.out_bf16 = yb; ep.ld_outb = M; } else { ep.out_f32 = y0; ep.ld_out = M; }
     RC(dense_fwd(in_proj_, W.x_bf16, Cp_, R, ep, st));
+    RC(join_update(st));
   }
 
   // DenseResBlocks (models/shared.py:61-75) each with its own FiLM generator (models/ncsn.py:47-61,
@@ -901,11 +951,27 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
       if (e != hipSuccess) { smd_set_error("loss_backward: %s", hipGetErrorString(e)); return (int)e; }
     }
     if (stage != 3) RC(backward_head(st));
-    if (stage == 1) RC(flush_ln_reduce(st));       // output-stage gradients must be final before the DP all-reduce
+    // opt_overlap bit 1 (single-process step, no all-reduce between this call and the optimiser): the output-stage slice of
+    // the gradient is final once its LayerNorm partials are reduced and its weight gradients are on the side stream, so its
+    // share of the global-norm partials is reduced THERE, underneath the encoder backward
+    const bool early_norm = stage == 0 && (opt_overlap & 2) && opt_fused_ok_ && side_wgrad && side_ && tr_path && head_off_ < n_params_;
+    head_norm_ready_ = false;
+    if (stage == 1 || early_norm) RC(flush_ln_reduce(st));       // output-stage gradients must be final before the DP all-reduce
     // the output stage's deferred wgrads (out_proj, up, FiLM generators) go to the side stream now: some of their operands
     // were produced THERE (the FiLM backward chain), and the step's last grouped launch -- which runs on the caller's
     // stream (tail_on_main) -- must only hold problems whose operands the caller's stream produced
     if (stage != 3) RC(flush_grouped_wgrads(st));
+    if (early_norm) {
+      if (!pending256_.empty()) RC(flush_pending256(st));
+      hipEvent_t ev = take_event();
+      SMD_ARG_CHECK(ev, "loss_backward: cannot create an event");
+      hipError_t e = hipEventRecord(ev, st);
+      if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
+      if (e != hipSuccess) { smd_set_error("loss_backward: event: %s", hipGetErrorString(e)); return (int)e; }
+      side_pending_ = true;
+      RC(launch_grad_sumsq_slots(grads_ + head_off_, (size_t)(n_params_ - head_off_), W.norm_partial, 512, side_));
+      head_norm_ready_ = true;
+    }
   }
   if (stage == 0 || stage == 2) {
     RC(backward_stem(st));
@@ -917,15 +983,49 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
 
 int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {
   SMD_ARG_CHECK(grads_ && params_, "optimizer_step: not bound");
+  SMD_ARG_CHECK(training_ && W.norm_partial, "optimizer_step: bind a training workspace first");
+  RC(join_update(st));
   AdamArgs a;
   a.params = params_; a.grads = grads_; a.m = m_; a.v = v_; a.ema = ema_; a.n = (size_t)n_params_;
   a.lr0 = h.lr0; a.lr_gamma = h.lr_gamma; a.lr_interval = h.lr_interval;
   a.beta1 = h.beta1; a.beta2 = h.beta2; a.eps = h.eps; a.grad_clip = h.grad_clip; a.mu = h.mu;
   a.grad_scale = h.grad_scale;
   a.step_ptr = step_ptr_; a.norm_partial = W.norm_partial; a.metrics_out = metrics_;
-  RC(launch_grad_sumsq(a, st));
-  RC(launch_adam_clip_ema(a, st));
-  return refresh_weights(st);
+  if (!opt_fused_ok_) {                       // table overflow (a very deep DenseDDPM): norm, update, re-cast as three passes
+    head_norm_ready_ = false;
+    RC(launch_grad_sumsq(a, st));
+    RC(launch_adam_clip_ema(a, st));
+    return refresh_weights(st);
+  }
+  // norm partials: slots [0, 512) = output-stage slice (already reduced on the side stream by loss_backward(stage 0) with
+  // opt_overlap bit 1 -- the join at the end of that call ordered `st` behind it), [512, 1024) = stem slice
+  const size_t n_head = (size_t)(n_params_ - head_off_), n_stem = (size_t)head_off_;
+  if (!head_norm_ready_) {
+    if (n_head) RC(launch_grad_sumsq_slots(grads_ + head_off_, n_head, W.norm_partial, 512, st));
+    else { hipError_t e = hipMemsetAsync(W.norm_partial, 0, 512 * sizeof(float), st); if (e != hipSuccess) { smd_set_error("optimizer_step: %s", hipGetErrorString(e)); return (int)e; } }
+  }
+  head_norm_ready_ = false;
+  if (n_stem) RC(launch_grad_sumsq_slots(grads_, n_stem, W.norm_partial + 512, 512, st));
+  else { hipError_t e = hipMemsetAsync(W.norm_partial + 512, 0, 512 * sizeof(float), st); if (e != hipSuccess) { smd_set_error("optimizer_step: %s", hipGetErrorString(e)); return (int)e; } }
+  RC(launch_opt_prepare(a, 1024, W.opt_consts, st));
+  RC(launch_adam_recast(a, W.opt_consts, wpack_, opt_stem_, st));
+  w8_dirty_ = true;
+  if ((opt_overlap & 1) && side_wgrad && side_ && opt_head_.total_blocks) {
+    // the output stage's 75 % of the bytes: on the side stream, underneath the next forward pass's encoder
+    hipEvent_t ev = take_event();
+    if (!head_done_ev_ && hipEventCreateWithFlags(&head_done_ev_, hipEventDisableTiming) != hipSuccess) head_done_ev_ = nullptr;
+    SMD_ARG_CHECK(ev && head_done_ev_, "optimizer_step: cannot create an event");
+    hipError_t e = hipEventRecord(ev, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
+    if (e != hipSuccess) { smd_set_error("optimizer_step: event: %s", hipGetErrorString(e)); return (int)e; }
+    RC(launch_adam_recast(a, W.opt_consts, wpack_, opt_head_, side_));
+    e = hipEventRecord(head_done_ev_, side_);
+    if (e != hipSuccess) { smd_set_error("optimizer_step: event: %s", hipGetErrorString(e)); return (int)e; }
+    head_pending_ = true;
+    next_event_ = 0;
+    return 0;
+  }
+  return launch_adam_recast(a, W.opt_consts, wpack_, opt_head_, st);
 }
 
 // ------------------------------------------------------------------ sampler

@@ -1,7 +1,12 @@
-// Fused multi-tensor optimiser over the flat fp32 parameter buffer (HBM-bound, 28 B/param):
-//   pass 1  grad_sumsq        per-block partial sums of g^2 (global L2 norm, deterministic order)
-//   pass 2  adam_clip_ema     clip_grads + Adam + stepped LR + EMA in one sweep
-//   pass 3  recast_weights    fp32 master -> bf16 GEMM operand copies in both layouts
+// Fused multi-tensor optimiser over the flat fp32 parameter buffer (HBM-bound, 28 B/param + 4 B/param of bf16 operands):
+//   pass 1  grad_sumsq_slots  per-block partial sums of g^2 into FIXED slots (global L2 norm, deterministic order); the
+//                             engine runs the output-stage slice's pass on its side stream under the encoder backward
+//   pass 2  opt_prepare       one workgroup: norm, clip factor, stepped LR, bias corrections -> 4 device constants; step += 1
+//   pass 3  adam_recast       clip_grads + Adam + EMA AND the bf16 re-cast of every Dense kernel in both operand layouts in
+//                             ONE sweep: a workgroup owns a 64 x 64 tile of a (K, N) kernel, a thread a 4 x 4 micro-tile that it
+//                             transposes in registers (no LDS, no second read of the 106 MB the update just wrote)
+// The engine-less entry point smd_adam_clip_ema keeps the plain flat kernels (grad_sumsq / adam_clip_ema), and
+// recast_all stays for loads / initialisation.
 //
 // Reference: jax.experimental.optimizers.clip_grads / l2_norm and flax.optim.Adam as used at
 // train_ncsn.py:284-287; stepped LR schedule train_ncsn.py:340-342; EMAHelper.update
@@ -190,7 +195,211 @@ __global__ __launch_bounds__(256) void recast_all_kernel(const float* __restrict
   }
 }
 
+// ---- engine path: fixed-slot norm partials, one-workgroup prepare, Adam + EMA + bf16 re-cast in one sweep ----------------
+// slot b of `partial` <- sum of g[i]^2 over block b's grid-stride share of [0, n): the same slots hold the same sums every
+// step whichever stream or order the slices were reduced in (bitwise repeatable norm)
+__global__ __launch_bounds__(256) void grad_sumsq_slots_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const size_t head = ((4 - (reinterpret_cast<uintptr_t>(g) >> 2 & 3)) & 3);        // scalars in front of the 16-byte boundary
+  const size_t h = head < n ? head : n;
+  const float* g4 = g + h;
+  const size_t n4 = (n - h) / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g4)[i];
+    acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < (int)h) { const float v = g[threadIdx.x]; acc += v * v; }
+    const size_t tail = n - h - n4 * 4;
+    if (threadIdx.x >= 64 && threadIdx.x - 64 < (int)tail) { const float v = g4[n4 * 4 + threadIdx.x - 64]; acc += v * v; }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+struct PrepDev {
+  float lr0, lr_gamma; int lr_interval;
+  float beta1, beta2, grad_clip, grad_scale;
+  uint32_t* step_ptr; const float* partial; int nslots;
+  float* consts; float* metrics_out;
+};
+
+// consts[0..3] = gradient multiplier (grad_scale * clip factor), lr, 1/(1-beta1^t), 1/(1-beta2^t); then *step_ptr += 1.
+// One workgroup sums the slots in a fixed order, so the norm is the same whoever launched it.
+__global__ __launch_bounds__(256) void opt_prepare_kernel(PrepDev a) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < a.nslots; i += 256) acc += a.partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]) * a.grad_scale;
+  // clip_grads: where(norm < max_norm, g, g * max_norm / norm)
+  const float gmul = a.grad_scale * (norm < a.grad_clip ? 1.0f : a.grad_clip / norm);
+  const uint32_t step = *a.step_ptr;
+  // stepped schedule: lr0 * gamma ** max(0, ceil(step/interval) - 1)
+  const int idx = (int)((step + (uint32_t)a.lr_interval - 1u) / (uint32_t)a.lr_interval) - 1;
+  const float lr = a.lr0 * powf(a.lr_gamma, (float)(idx > 0 ? idx : 0));
+  const float tt = (float)(step + 1u);
+  const float bc1 = 1.0f - powf(a.beta1, tt), bc2 = 1.0f - powf(a.beta2, tt);
+  a.consts[0] = gmul; a.consts[1] = lr; a.consts[2] = 1.0f / bc1; a.consts[3] = 1.0f / bc2;
+  if (a.metrics_out) {
+    a.metrics_out[0] = norm;
+    a.metrics_out[1] = norm < a.grad_clip ? norm : a.grad_clip;   // l2_norm of the clipped grads
+    a.metrics_out[2] = lr;
+    a.metrics_out[3] = (float)step;
+  }
+  *a.step_ptr = step + 1u;
+}
+
+struct AdamTileDev {
+  float* p; const float* g; float* m; float* v; float* ema;
+  bf16_t* wpack;
+  const float* consts;
+  float beta1, beta2, eps, mu;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float gmul, float lr, float inv_bc1, float inv_bc2,
+                                          float beta1, float ob1, float beta2, float ob2, float eps) {
+  const float gk = g * gmul;
+  m = beta1 * m + ob1 * gk;
+  v = beta2 * v + ob2 * gk * gk;
+  p -= lr * (m * inv_bc1) / (sqrtf(v * inv_bc2) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_recast_kernel(AdamTileDev a, OptTable t) {
+  const float gmul = a.consts[0], lr = a.consts[1], inv_bc1 = a.consts[2], inv_bc2 = a.consts[3];
+  const float ob1 = 1.0f - a.beta1, ob2 = 1.0f - a.beta2, omu = 1.0f - a.mu;
+  const uint32_t b = blockIdx.x;
+  if (b >= t.flat_blk0) {
+    // biases / LayerNorm parameters: 1024 elements per workgroup, any alignment
+    int si = 0;
+#pragma unroll 1
+    for (int i = 1; i < t.n_flat; ++i)
+      if (b >= t.f[i].blk_start) si = i;
+    const OptFlat f = t.f[si];
+    const uint32_t base = (b - f.blk_start) * 1024u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t e = base + j * 256u + threadIdx.x;
+      if (e < f.len) {
+        const size_t i = (size_t)f.off + e;
+        float p = a.p[i], m = a.m[i], v = a.v[i];
+        adam_elem(p, a.g[i], m, v, gmul, lr, inv_bc1, inv_bc2, a.beta1, ob1, a.beta2, ob2, a.eps);
+        a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        if (a.ema) a.ema[i] = a.ema[i] * a.mu + p * omu;
+      }
+    }
+    return;
+  }
+  int wi = 0;
+#pragma unroll 1
+  for (int i = 1; i < t.n_dense; ++i)
+    if (b >= t.d[i].blk_start) wi = i;
+  const OptDense e = t.d[wi];
+  const uint32_t local = b - e.blk_start;
+  const uint32_t tiles_n = (e.N + 63u) / 64u;
+  const int k0 = (int)(local / tiles_n) * 64, n0 = (int)(local % tiles_n) * 64;
+  const int cq = threadIdx.x & 15, kq = threadIdx.x >> 4;                 // this thread: rows k0 + 4 kq .. +3, columns n0 + 4 cq .. +3
+  const int kb = k0 + 4 * kq, nb = n0 + 4 * cq;
+  const size_t wo = (size_t)e.w_off;
+  float pv[4][4], gv[4][4], mv[4][4], vv[4][4], ev[4][4];
+  const bool fast = k0 + 64 <= (int)e.K && n0 + 64 <= (int)e.N && ((e.w_off | e.N | e.W_off | e.ldw | e.Wt_off | e.ldwt) & 3u) == 0;
+  if (fast) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t o = wo + (size_t)(kb + i) * e.N + nb;
+      *reinterpret_cast<float4*>(pv[i]) = *reinterpret_cast<const float4*>(a.p + o);
+      *reinterpret_cast<float4*>(gv[i]) = *reinterpret_cast<const float4*>(a.g + o);
+      *reinterpret_cast<float4*>(mv[i]) = *reinterpret_cast<const float4*>(a.m + o);
+      *reinterpret_cast<float4*>(vv[i]) = *reinterpret_cast<const float4*>(a.v + o);
+      if (a.ema) *reinterpret_cast<float4*>(ev[i]) = *reinterpret_cast<const float4*>(a.ema + o);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) adam_elem(pv[i][j], gv[i][j], mv[i][j], vv[i][j], gmul, lr, inv_bc1, inv_bc2, a.beta1, ob1, a.beta2, ob2, a.eps);
+    bf16_t* W = a.wpack + e.W_off;
+    bf16_t* Wt = a.wpack + e.Wt_off;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t o = wo + (size_t)(kb + i) * e.N + nb;
+      *reinterpret_cast<float4*>(a.p + o) = *reinterpret_cast<float4*>(pv[i]);
+      *reinterpret_cast<float4*>(a.m + o) = *reinterpret_cast<float4*>(mv[i]);
+      *reinterpret_cast<float4*>(a.v + o) = *reinterpret_cast<float4*>(vv[i]);
+      if (a.ema) {
+        float4 q;
+        q.x = ev[i][0] * a.mu + pv[i][0] * omu; q.y = ev[i][1] * a.mu + pv[i][1] * omu;
+        q.z = ev[i][2] * a.mu + pv[i][2] * omu; q.w = ev[i][3] * a.mu + pv[i][3] * omu;
+        *reinterpret_cast<float4*>(a.ema + o) = q;
+      }
+      bf16x4_t w;
+      w[0] = f2bf(pv[i][0]); w[1] = f2bf(pv[i][1]); w[2] = f2bf(pv[i][2]); w[3] = f2bf(pv[i][3]);
+      *reinterpret_cast<bf16x4_t*>(W + (size_t)(kb + i) * e.ldw + nb) = w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // the transposed layout: row n, four consecutive k
+      bf16x4_t w;
+      w[0] = f2bf(pv[0][j]); w[1] = f2bf(pv[1][j]); w[2] = f2bf(pv[2][j]); w[3] = f2bf(pv[3][j]);
+      *reinterpret_cast<bf16x4_t*>(Wt + (size_t)(nb + j) * e.ldwt + kb) = w;
+    }
+    return;
+  }
+  // edge tiles and kernels whose rows are not 16-byte aligned (C = 42, 146): element by element
+  bf16_t* W = a.wpack + e.W_off;
+  bf16_t* Wt = a.wpack + e.Wt_off;
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i)
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+      const int k = kb + i, n = nb + j;
+      if (k >= (int)e.K || n >= (int)e.N) continue;
+      const size_t o = wo + (size_t)k * e.N + n;
+      float p = a.p[o], m = a.m[o], v = a.v[o];
+      adam_elem(p, a.g[o], m, v, gmul, lr, inv_bc1, inv_bc2, a.beta1, ob1, a.beta2, ob2, a.eps);
+      a.p[o] = p; a.m[o] = m; a.v[o] = v;
+      if (a.ema) a.ema[o] = a.ema[o] * a.mu + p * omu;
+      W[(size_t)k * e.ldw + n] = f2bf(p);
+      Wt[(size_t)n * e.ldwt + k] = f2bf(p);
+    }
+}
+
 }  // namespace
+
+int launch_grad_sumsq_slots(const float* g, size_t n, float* partial, int nslots, hipStream_t st) {
+  SMD_ARG_CHECK(g && partial && n > 0 && nslots > 0, "grad_sumsq_slots: bad arguments");
+  hipLaunchKernelGGL(grad_sumsq_slots_kernel, dim3(nslots), dim3(256), 0, st, g, n, partial);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_opt_prepare(const AdamArgs& a, int nslots, float* consts, hipStream_t st) {
+  SMD_ARG_CHECK(a.step_ptr && a.norm_partial && consts && nslots > 0, "opt_prepare: null pointer");
+  SMD_ARG_CHECK(a.lr_interval > 0, "opt_prepare: lr_interval must be positive");
+  PrepDev d;
+  d.lr0 = a.lr0; d.lr_gamma = a.lr_gamma; d.lr_interval = a.lr_interval; d.beta1 = a.beta1; d.beta2 = a.beta2;
+  d.grad_clip = a.grad_clip; d.grad_scale = a.grad_scale; d.step_ptr = a.step_ptr; d.partial = a.norm_partial; d.nslots = nslots;
+  d.consts = consts; d.metrics_out = a.metrics_out;
+  hipLaunchKernelGGL(opt_prepare_kernel, dim3(1), dim3(256), 0, st, d);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_adam_recast(const AdamArgs& a, const float* consts, bf16_t* wpack, const OptTable& t, hipStream_t st) {
+  SMD_ARG_CHECK(a.params && a.grads && a.m && a.v && consts && wpack, "adam_recast: null pointer");
+  SMD_ARG_CHECK(t.n_dense >= 0 && t.n_dense <= SMD_OPT_DENSE_MAX && t.n_flat >= 0 && t.n_flat <= SMD_OPT_FLAT_MAX, "adam_recast: bad table");
+  if (t.total_blocks == 0) return 0;
+  AdamTileDev d;
+  d.p = a.params; d.g = a.grads; d.m = a.m; d.v = a.v; d.ema = a.ema; d.wpack = wpack; d.consts = consts;
+  d.beta1 = a.beta1; d.beta2 = a.beta2; d.eps = a.eps; d.mu = a.mu;
+  hipLaunchKernelGGL(adam_recast_kernel, dim3(t.total_blocks), dim3(256), 0, st, d, t);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_recast_all(const float* params, bf16_t* wpack, const RecastTable& t, int total_tiles, hipStream_t st) {
   SMD_ARG_CHECK(params && wpack && t.n > 0 && t.n <= SMD_RECAST_MAX && total_tiles > 0, "recast_all: bad arguments");

@@ -51,9 +51,29 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _joined(name: str) -> property:
+    """Buffer attribute whose READ first orders the current stream behind a deferred output-stage optimiser update (any
+    handle on the same parameters): ``opt_overlap`` lets the 75 % of the update that the next forward pass does not need
+    until its `up` projection run on the engine's side stream, so everything that looks at the parameters, the Adam state,
+    the EMA or the operand pack through Python -- another handle, a checkpoint, a test -- joins here."""
+    def get(self):
+        self._join_pending()
+        return self.__dict__.get("_buf_" + name)
+
+    def set(self, value):
+        self.__dict__["_buf_" + name] = value
+    return property(get, set)
+
+
 class Engine:
     """One engine handle + its parameter buffers.  ``bind(batch, training)`` (re)allocates the
     activation workspace for a batch size / mode."""
+    params = _joined("params")
+    wpack = _joined("wpack")
+    grads = _joined("grads")
+    m = _joined("m")
+    v = _joined("v")
+    ema = _joined("ema")
 
     def __init__(self, cfg: NetConfig, device: str = "cuda:0", share_params_with: Optional["Engine"] = None):
         if cfg.architecture not in ARCH_IDS:
@@ -92,8 +112,9 @@ class Engine:
                 self.wpack = torch.zeros(int(self.L.smd_engine_wpack_elems(h)), dtype=torch.int16, device=self.device)
             _lib.check(self.L.smd_engine_bind_params(h, _ptr(self.params), _ptr(self.wpack)), "bind_params")
         # engines sharing one operand pack: a weight refresh through any handle invalidates every handle's e4m3 copies
-        self._wstate = share_params_with._wstate if share_params_with is not None else {"ver": 0}
+        self._wstate = share_params_with._wstate if share_params_with is not None else {"ver": 0, "pending": None}
         self._wseen = -1
+        self._opt_overlap = 0
         for kv in filter(None, os.environ.get("SMD_ENGINE_OPTS", "").split(",")):      # A/B runs: "key=value,key=value"
             k, _, v = kv.partition("=")
             _lib.check(self.L.smd_engine_set_option(h, k.strip().encode(), int(v)), f"SMD_ENGINE_OPTS {kv}")
@@ -107,6 +128,25 @@ class Engine:
         self.training = False
         self._sched_tensors = None
         self.betas = None
+
+    def _join_pending(self) -> None:
+        """Order the current stream behind a deferred output-stage update of whichever handle shares these buffers."""
+        ws = self.__dict__.get("_wstate")
+        if not ws:
+            return
+        p = ws.get("pending")
+        if p is not None and getattr(p, "h", None):
+            ws["pending"] = None
+            with torch.cuda.device(p.device):
+                _lib.check(p.L.smd_engine_join_update(p.h, _stream()), "join_update")
+
+    def set_opt_overlap(self, value: int) -> None:
+        """Engine option "opt_overlap" (include/smd_hip.h): bit 0 defers the output-stage update to the side stream, bit 1
+        reduces that slice's norm partials early.  SMD_OPT_OVERLAP in the environment overrides (A/B runs)."""
+        value = int(os.environ.get("SMD_OPT_OVERLAP", value))
+        if value != self._opt_overlap:
+            self.set_option("opt_overlap", value)
+            self._opt_overlap = value
 
     def __del__(self):
         try:
@@ -158,6 +198,7 @@ class Engine:
         self.refresh_weights()
 
     def refresh_weights(self) -> None:
+        self._join_pending()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_refresh_weights(self.h, _stream()), "refresh_weights")
         self._wstate["ver"] += 1
@@ -249,6 +290,7 @@ class Engine:
             raise ValueError(f"noise level has {s.numel()} entries for batch {B}")
         self.bind(B, training=False)
         self._sync_fp8_weights()
+        self._join_pending()
         out = torch.empty_like(x)
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_forward(self.h, _ptr(x), _ptr(s), _ptr(out), _stream()), "forward")
@@ -284,8 +326,13 @@ class Engine:
                        mu: float = 0.999, grad_scale: float = 1.0, beta1: float = 0.9, beta2: float = 0.999,
                        eps: float = 1e-8) -> None:
         h = _lib.TrainHyper(lr0, lr_gamma, lr_interval, beta1, beta2, eps, grad_clip, mu, grad_scale)
+        p = self._wstate.get("pending")
+        if p is not None and p is not self:
+            self._join_pending()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_optimizer_step(self.h, C.byref(h), _stream()), "optimizer_step")
+        if self._opt_overlap & 1:
+            self._wstate["pending"] = self      # output-stage slice still in flight on this handle's side stream
         self._wstate["ver"] += 1            # the step re-casts the operand pack (this handle re-quantises itself)
         self._wseen = self._wstate["ver"]
 
@@ -307,6 +354,7 @@ class Engine:
     def prepare_sampler(self) -> None:
         if self._sched_tensors is None or self._sched_tensors["film"] is None:
             raise RuntimeError("set_schedule(betas, with_sampler=True) first")
+        self._join_pending()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_prepare_sampler(self.h, _stream()), "prepare_sampler")
 
@@ -321,6 +369,7 @@ class Engine:
 
     def sample_step(self, io: "_lib.SampleIO") -> None:
         self._sync_fp8_weights()
+        self._join_pending()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_sample_step(self.h, C.byref(io), _stream()), "sample_step")
 

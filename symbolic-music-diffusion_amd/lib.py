@@ -54,7 +54,7 @@ class LangevinIO(C.Structure):
                 ("steps_per_level", c_i32), ("n_levels", c_i32)]
 
 
-ABI_VERSION = 3          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
+ABI_VERSION = 4          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
 
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
 _SIGS = {
@@ -87,6 +87,7 @@ _SIGS = {
     "smd_engine_loss_per_sample": (c_void, [c_void]),
     "smd_engine_pred": (c_void, [c_void]),
     "smd_engine_optimizer_step": (C.c_int, [c_void, C.POINTER(TrainHyper), c_void]),
+    "smd_engine_join_update": (C.c_int, [c_void, c_void]),
     "smd_engine_prepare_sampler": (C.c_int, [c_void, c_void]),
     "smd_engine_init_state": (C.c_int, [c_void, c_void, c_u32, c_u32, c_u32, c_void]),
     "smd_engine_load_state": (C.c_int, [c_void, c_void, c_void]),

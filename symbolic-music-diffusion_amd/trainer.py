@@ -110,6 +110,9 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
                                             global_batch=gb)
     kw = dict(seed=rng.seed, sample_offset=sample_offset, global_batch=gb, used_alphas=ua, continuous_noise=continuous_noise,
               objective="dsm" if dsm else "ddpm")
+    # optimiser placement (engine option "opt_overlap"): the output-stage slice of the update runs on the engine's side stream
+    # underneath the next step's encoder forward; without a communicator that slice's norm partials are reduced early too
+    eng.set_opt_overlap(3 if comm is None else 1)
     if comm is None:
         eng.loss_backward(batch, lab, e, stage=0, **kw)
     else:

@@ -190,5 +190,5 @@ def test_fp8_forward_and_train_step_parity(B, L_, H, K_, C):
           f"{e_g:.3e}, worst tensor {w_name} {w_g:.3e} (bf16 dgrads: {e_gb:.3e})")
     assert abs(m_eng - m_ref) / m_ref < 2e-2
     assert e_g < GRAD_TOL and e_gb < GRAD_TOL
-    assert w_g < 0.25
+    assert w_g < 0.15                                       # measured <= 4.9e-2 (a FiLM LayerNorm scale / bias)
     assert not torch.equal(g8, eng.grads)                   # the e4m3 dgrad path really ran
