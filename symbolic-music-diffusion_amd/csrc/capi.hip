@@ -99,6 +99,8 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8_dgrad") { e->impl.fp8_dgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "opt_overlap") { e->impl.opt_overlap = value & 3; return 0; }
+  if (std::string(key) == "opt_fused") { e->impl.set_opt_fused(value != 0); return 0; }     // 0: norm / update / re-cast as three passes (A/B)
+  if (std::string(key) == "opt_side_blocks") { e->impl.opt_side_blocks = value < 0 ? 0 : value; return 0; }
   if (std::string(key) == "w8_dirty") { e->impl.mark_w8_dirty(); return 0; }   // the bf16 operand pack changed under another handle
   smd_set_error("set_option: unknown key '%s'", key);
   return -1;

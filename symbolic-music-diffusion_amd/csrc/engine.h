@@ -108,6 +108,8 @@ class SmdEngine {
   //          gradient between the two calls (no all-reduce: the data-parallel path leaves this bit off).
   // 0 (default): everything on the caller's stream, complete in stream order when optimizer_step returns.
   int opt_overlap = 0;
+  int opt_side_blocks = 0;              // > 0: workgroups of the deferred output-stage sweep (grid-stride: throttles its HBM rate); 0 = one per tile
+  void set_opt_fused(bool on) { opt_fused_user_ = on; }
   int join_update(hipStream_t st);      // make `st` wait for a deferred output-stage update (no-op when none is pending)
   int prepare_sampler(hipStream_t st);                       // FiLM tables for every timestep
   int sample_step(const SampleStepIO& io, hipStream_t st);   // eps-net forward + fused reverse step
@@ -227,7 +229,8 @@ class SmdEngine {
   OptTable opt_stem_, opt_head_;               // tile tables of the fused optimiser sweep (parameters < / >= head_off_)
   void build_opt_tables();
   bool opt_fused_ok_ = true;
-  bool head_norm_ready_ = false;               // slots [0, 512) of norm_partial hold this step's output-stage partials (side stream)
+  bool opt_fused_user_ = true;                 // option "opt_fused": false forces the three-pass fallback (A/B runs)
+  bool head_norm_ready_ = false;               // the head slots of norm_partial hold this step's output-stage partials (side stream)
   bool head_pending_ = false;                  // an output-stage update is in flight on the side stream
   hipEvent_t head_done_ev_ = nullptr;          // recorded behind it (owned; not from the recycled pool)
 
@@ -281,7 +284,7 @@ class SmdEngine {
     float* tn_slab = nullptr;             // split-K partial tiles of the wgrad kernel (main stream)
     float* tn_slab_side = nullptr;        // the same for wgrads issued on the side stream
     size_t tn_slab_elems = 0;
-    float* norm_partial = nullptr;        // [1024]: slots [0, 512) output-stage slice, [512, 1024) stem slice
+    float* norm_partial = nullptr;        // [SMD_NORM_SLOTS]: slots [0, SMD_NORM_HEAD_SLOTS) output-stage slice, the rest stem slice
     float* opt_consts = nullptr;          // [8]: clip multiplier, lr, 1/(1-b1^t), 1/(1-b2^t) of the current update
     bf16_t* zero_page = nullptr;          // [128]
     unsigned* step_arrive = nullptr;      // [64] arrival counter of the fused reverse step

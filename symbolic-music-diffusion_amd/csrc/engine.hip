@@ -371,7 +371,7 @@ int64_t SmdEngine::plan(void* base, int batch, int training, Work* w) const {
     t.tn_slab_elems = gemm_tn_slab_elems();
     t.tn_slab = c.take<float>(t.tn_slab_elems);
     t.tn_slab_side = c.take<float>(t.tn_slab_elems);
-    t.norm_partial = c.take<float>(1024);
+    t.norm_partial = c.take<float>(SMD_NORM_SLOTS);
     t.opt_consts = c.take<float>(8);
     const size_t Mp = (R + 63) / 64 * 64;
     t.tn_scratch_elems = tr_path ? 0 : (size_t)2 * (2 * M) * Mp;
@@ -954,7 +954,7 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     // opt_overlap bit 1 (single-process step, no all-reduce between this call and the optimiser): the output-stage slice of
     // the gradient is final once its LayerNorm partials are reduced and its weight gradients are on the side stream, so its
     // share of the global-norm partials is reduced THERE, underneath the encoder backward
-    const bool early_norm = stage == 0 && (opt_overlap & 2) && opt_fused_ok_ && side_wgrad && side_ && tr_path && head_off_ < n_params_;
+    const bool early_norm = stage == 0 && (opt_overlap & 2) && opt_fused_ok_ && opt_fused_user_ && side_wgrad && side_ && tr_path && head_off_ < n_params_;
     head_norm_ready_ = false;
     if (stage == 1 || early_norm) RC(flush_ln_reduce(st));       // output-stage gradients must be final before the DP all-reduce
     // the output stage's deferred wgrads (out_proj, up, FiLM generators) go to the side stream now: some of their operands
@@ -969,7 +969,7 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
       if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
       if (e != hipSuccess) { smd_set_error("loss_backward: event: %s", hipGetErrorString(e)); return (int)e; }
       side_pending_ = true;
-      RC(launch_grad_sumsq_slots(grads_ + head_off_, (size_t)(n_params_ - head_off_), W.norm_partial, 512, side_));
+      RC(launch_grad_sumsq_slots(grads_ + head_off_, (size_t)(n_params_ - head_off_), W.norm_partial, SMD_NORM_HEAD_SLOTS, side_));
       head_norm_ready_ = true;
     }
   }
@@ -991,23 +991,23 @@ int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {
   a.beta1 = h.beta1; a.beta2 = h.beta2; a.eps = h.eps; a.grad_clip = h.grad_clip; a.mu = h.mu;
   a.grad_scale = h.grad_scale;
   a.step_ptr = step_ptr_; a.norm_partial = W.norm_partial; a.metrics_out = metrics_;
-  if (!opt_fused_ok_) {                       // table overflow (a very deep DenseDDPM): norm, update, re-cast as three passes
+  if (!opt_fused_ok_ || !opt_fused_user_) {   // table overflow (a very deep DenseDDPM): norm, update, re-cast as three passes
     head_norm_ready_ = false;
     RC(launch_grad_sumsq(a, st));
     RC(launch_adam_clip_ema(a, st));
     return refresh_weights(st);
   }
-  // norm partials: slots [0, 512) = output-stage slice (already reduced on the side stream by loss_backward(stage 0) with
-  // opt_overlap bit 1 -- the join at the end of that call ordered `st` behind it), [512, 1024) = stem slice
+  // norm partials: slots [0, SMD_NORM_HEAD_SLOTS) = output-stage slice (already reduced on the side stream by loss_backward(stage 0)
+  // with opt_overlap bit 1 -- the join at the end of that call ordered `st` behind it), the rest = stem slice
   const size_t n_head = (size_t)(n_params_ - head_off_), n_stem = (size_t)head_off_;
   if (!head_norm_ready_) {
-    if (n_head) RC(launch_grad_sumsq_slots(grads_ + head_off_, n_head, W.norm_partial, 512, st));
-    else { hipError_t e = hipMemsetAsync(W.norm_partial, 0, 512 * sizeof(float), st); if (e != hipSuccess) { smd_set_error("optimizer_step: %s", hipGetErrorString(e)); return (int)e; } }
+    if (n_head) RC(launch_grad_sumsq_slots(grads_ + head_off_, n_head, W.norm_partial, SMD_NORM_HEAD_SLOTS, st));
+    else { hipError_t e = hipMemsetAsync(W.norm_partial, 0, SMD_NORM_HEAD_SLOTS * sizeof(float), st); if (e != hipSuccess) { smd_set_error("optimizer_step: %s", hipGetErrorString(e)); return (int)e; } }
   }
   head_norm_ready_ = false;
-  if (n_stem) RC(launch_grad_sumsq_slots(grads_, n_stem, W.norm_partial + 512, 512, st));
-  else { hipError_t e = hipMemsetAsync(W.norm_partial + 512, 0, 512 * sizeof(float), st); if (e != hipSuccess) { smd_set_error("optimizer_step: %s", hipGetErrorString(e)); return (int)e; } }
-  RC(launch_opt_prepare(a, 1024, W.opt_consts, st));
+  if (n_stem) RC(launch_grad_sumsq_slots(grads_, n_stem, W.norm_partial + SMD_NORM_HEAD_SLOTS, SMD_NORM_SLOTS - SMD_NORM_HEAD_SLOTS, st));
+  else { hipError_t e = hipMemsetAsync(W.norm_partial + SMD_NORM_HEAD_SLOTS, 0, (SMD_NORM_SLOTS - SMD_NORM_HEAD_SLOTS) * sizeof(float), st); if (e != hipSuccess) { smd_set_error("optimizer_step: %s", hipGetErrorString(e)); return (int)e; } }
+  RC(launch_opt_prepare(a, SMD_NORM_SLOTS, W.opt_consts, st));
   RC(launch_adam_recast(a, W.opt_consts, wpack_, opt_stem_, st));
   w8_dirty_ = true;
   if ((opt_overlap & 1) && side_wgrad && side_ && opt_head_.total_blocks) {
@@ -1018,7 +1018,7 @@ int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {
     hipError_t e = hipEventRecord(ev, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(side_, ev, 0);
     if (e != hipSuccess) { smd_set_error("optimizer_step: event: %s", hipGetErrorString(e)); return (int)e; }
-    RC(launch_adam_recast(a, W.opt_consts, wpack_, opt_head_, side_));
+    RC(launch_adam_recast(a, W.opt_consts, wpack_, opt_head_, side_, opt_side_blocks));
     e = hipEventRecord(head_done_ev_, side_);
     if (e != hipSuccess) { smd_set_error("optimizer_step: event: %s", hipGetErrorString(e)); return (int)e; }
     head_pending_ = true;

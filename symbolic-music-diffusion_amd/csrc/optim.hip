@@ -271,10 +271,9 @@ __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v,
   p -= lr * (m * inv_bc1) / (sqrtf(v * inv_bc2) + eps);
 }
 
-__global__ __launch_bounds__(256) void adam_recast_kernel(AdamTileDev a, OptTable t) {
-  const float gmul = a.consts[0], lr = a.consts[1], inv_bc1 = a.consts[2], inv_bc2 = a.consts[3];
+__device__ __forceinline__ void adam_recast_block(const AdamTileDev& a, const OptTable& t, uint32_t b, float gmul, float lr, float inv_bc1,
+                                                  float inv_bc2) {
   const float ob1 = 1.0f - a.beta1, ob2 = 1.0f - a.beta2, omu = 1.0f - a.mu;
-  const uint32_t b = blockIdx.x;
   if (b >= t.flat_blk0) {
     // biases / LayerNorm parameters: 1024 elements per workgroup, any alignment
     int si = 0;
@@ -368,6 +367,15 @@ __global__ __launch_bounds__(256) void adam_recast_kernel(AdamTileDev a, OptTabl
     }
 }
 
+// one work item per workgroup (gridDim.x == t.total_blocks), or a grid-stride walk of fewer workgroups: the deferred
+// output-stage update runs THROTTLED on the side stream (a fraction of the HBM rate for a longer time) so that the
+// latency-bound encoder kernels of the next forward pass keep their memory latency
+__global__ __launch_bounds__(256) void adam_recast_kernel(AdamTileDev a, OptTable t) {
+  const float gmul = a.consts[0], lr = a.consts[1], inv_bc1 = a.consts[2], inv_bc2 = a.consts[3];
+#pragma unroll 1
+  for (uint32_t b = blockIdx.x; b < t.total_blocks; b += gridDim.x) adam_recast_block(a, t, b, gmul, lr, inv_bc1, inv_bc2);
+}
+
 }  // namespace
 
 int launch_grad_sumsq_slots(const float* g, size_t n, float* partial, int nslots, hipStream_t st) {
@@ -389,14 +397,15 @@ int launch_opt_prepare(const AdamArgs& a, int nslots, float* consts, hipStream_t
   return 0;
 }
 
-int launch_adam_recast(const AdamArgs& a, const float* consts, bf16_t* wpack, const OptTable& t, hipStream_t st) {
+int launch_adam_recast(const AdamArgs& a, const float* consts, bf16_t* wpack, const OptTable& t, hipStream_t st, int max_blocks) {
   SMD_ARG_CHECK(a.params && a.grads && a.m && a.v && consts && wpack, "adam_recast: null pointer");
   SMD_ARG_CHECK(t.n_dense >= 0 && t.n_dense <= SMD_OPT_DENSE_MAX && t.n_flat >= 0 && t.n_flat <= SMD_OPT_FLAT_MAX, "adam_recast: bad table");
   if (t.total_blocks == 0) return 0;
   AdamTileDev d;
   d.p = a.params; d.g = a.grads; d.m = a.m; d.v = a.v; d.ema = a.ema; d.wpack = wpack; d.consts = consts;
   d.beta1 = a.beta1; d.beta2 = a.beta2; d.eps = a.eps; d.mu = a.mu;
-  hipLaunchKernelGGL(adam_recast_kernel, dim3(t.total_blocks), dim3(256), 0, st, d, t);
+  const unsigned grid = max_blocks > 0 && (unsigned)max_blocks < t.total_blocks ? (unsigned)max_blocks : t.total_blocks;
+  hipLaunchKernelGGL(adam_recast_kernel, dim3(grid), dim3(256), 0, st, d, t);
   SMD_LAUNCH_CHECK();
   return 0;
 }

@@ -337,6 +337,8 @@ int launch_grad_sumsq(const AdamArgs& a, hipStream_t st);
 int launch_adam_clip_ema(const AdamArgs& a, hipStream_t st);
 // engine path (optim.hip): norm partials in fixed slots, one-workgroup prepare (norm -> clip factor, LR, bias corrections in
 // consts[0..3]; *step_ptr += 1), and clip + Adam + EMA + bf16 re-cast of the Dense kernels in one sweep over a tile table
+#define SMD_NORM_SLOTS 2048        // one workgroup of the partial-sum pass per slot: 1536 for the output-stage slice, 512 for the stem
+#define SMD_NORM_HEAD_SLOTS 1536
 #define SMD_OPT_DENSE_MAX 60
 #define SMD_OPT_FLAT_MAX 64
 struct OptDense { uint32_t w_off, K, N, W_off, ldw, Wt_off, ldwt, blk_start; };   // one (K, N) Dense kernel: 64 x 64 tiles from blk_start
@@ -349,7 +351,7 @@ struct OptTable {
 };
 int launch_grad_sumsq_slots(const float* g, size_t n, float* partial, int nslots, hipStream_t st);
 int launch_opt_prepare(const AdamArgs& a, int nslots, float* consts, hipStream_t st);
-int launch_adam_recast(const AdamArgs& a, const float* consts, bf16_t* wpack, const OptTable& t, hipStream_t st);
+int launch_adam_recast(const AdamArgs& a, const float* consts, bf16_t* wpack, const OptTable& t, hipStream_t st, int max_blocks = 0);
 
 // master fp32 kernel (K_in, N_out) -> bf16 W [Kp][ldw] (zero padded) and Wt [N_out][ldwt]
 int launch_recast_weight(const float* w, int K_in, int N_out, bf16_t* W, int ldw, bf16_t* Wt, int ldwt,

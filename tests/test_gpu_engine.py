@@ -195,6 +195,62 @@ def test_optimizer_step_matches_oracle():
     assert rel(model(x, s), ref) < 1e-2
 
 
+@pytest.mark.parametrize("arch,C,L,K,B", [("TransformerDDPM", 512, 6, 2, 256), ("TransformerDDPM", 42, 2, 1, 4), ("TransformerDDPM", 146, 2, 3, 4),
+                                          ("DenseDDPM", 42, 3, 2, 8), ("DenseDDPM", 512, 2, 2, 64)])
+def test_one_sweep_optimizer_recast_and_overlap_modes(arch, C, L, K, B, monkeypatch):
+    """train_ncsn.py:284-287 as ONE sweep (csrc/optim.hip adam_recast_kernel): clip + Adam + EMA and the bf16 re-cast of every
+    Dense kernel in both operand layouts per 64 x 64 tile.
+      (a) the operand pack the sweep leaves equals a fresh re-cast of the updated fp32 master, bit for bit (aligned tiles, the
+          ragged in_proj / out_proj kernels of C = 42 / 146, DenseDDPM);
+      (b) engine option "opt_overlap": 0 (everything on the caller's stream), 1 (output-stage slice of the update on the side
+          stream under the next forward pass), 3 (+ that slice's norm partials reduced early on the side stream) give bitwise
+          the same 4-step trajectory -- parameters, Adam moments, EMA, operand pack, metrics, losses;
+      (c) another handle on the same buffers (the inference engine) called straight after a step with a deferred update sees
+          the finished update (Python-side join)."""
+    import smd_amd.ncsn as N
+    from smd_amd.trainer import create_optimizer, train_step
+    _, p, model = make(arch, C, L, 8, K)
+    shape = (C,) if arch == "DenseDDPM" else (32, C)
+    x0, g = data(B, shape)
+    xd = x0.cuda()
+    opt = create_optimizer(model, 1e-3, ema=True)
+    eng = opt.engine
+    start = eng.params.clone()
+    xs = torch.clamp(0.25 * torch.randn(3, *shape, generator=g), -1, 1)
+    ss = torch.tensor([0.3, 0.6, 0.9]).view(3, *([1] * len(shape)))
+
+    def trajectory(mode):
+        monkeypatch.setenv("SMD_OPT_OVERLAP", str(mode))
+        eng.params.copy_(start)
+        eng.m.zero_(); eng.v.zero_(); eng.ema.copy_(start); eng.step_counter.zero_()
+        eng.refresh_weights()
+        losses, mets = [], []
+        for i in range(4):
+            # interval 2 / gamma .5: the stepped LR changes inside the run; clip 0.5 (the norm is ~1): the clip branch is taken
+            _, m = train_step(N.diffusion_loss, xd, opt, BETAS, N.PRNGKey(11), 1e-3, grad_clip=0.5, lr_gamma=0.5, lr_interval=2)
+            losses.append(m["loss"].clone()); mets.append(eng.metrics.clone())
+        out = model(xs, ss)                                   # (c): no synchronize between the deferred update and this call
+        torch.cuda.synchronize()
+        assert torch.equal(out, model(xs, ss))
+        return dict(params=eng.params.clone(), m=eng.m.clone(), v=eng.v.clone(), ema=eng.ema.clone(), wpack=eng.wpack.clone(),
+                    losses=torch.stack(losses), metrics=torch.stack(mets), step=int(eng.step_counter.item()))
+
+    ref = trajectory(0)
+    assert ref["step"] == 4 and not torch.equal(ref["params"], start) and bool(torch.isfinite(ref["params"]).all())
+    assert float(ref["metrics"][0, 0]) > 0.5 and abs(float(ref["metrics"][0, 1]) - 0.5) < 1e-6          # clipped to 0.5
+    assert abs(float(ref["metrics"][3, 2]) / float(ref["metrics"][0, 2]) - 0.5) < 1e-6                  # lr halved by step 3
+    # (a)
+    pack = ref["wpack"]
+    eng.refresh_weights()
+    torch.cuda.synchronize()
+    assert torch.equal(pack, eng.wpack), "the fused re-cast differs from recast_all of the same parameters"
+    for mode in (1, 3):
+        got = trajectory(mode)
+        for k in ref:
+            same = got[k] == ref[k] if k == "step" else torch.equal(got[k], ref[k])
+            assert same, f"opt_overlap={mode}: {k} differs from the single-stream trajectory"
+
+
 def test_first_adam_step_is_lr_sign():
     _, p, model = make(C=42, L=2, K=1)
     eng = model.train_engine(ema=False)
