@@ -147,7 +147,7 @@ template <int V, bool F8>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict__ Av, int lda,
                                                          const void* __restrict__ Btv, int ldb, int M, int N, int K,
                                                          int tiles_n, int nwg, GemmEpilogue ep,
-                                                         const uint32_t* __restrict__ scale_a, const uint32_t* __restrict__ scale_b) {
+                                                         const uint32_t* __restrict__ scale_a, const uint32_t* __restrict__ scale_b, int pk_epi) {
   constexpr int ESZ = F8 ? 1 : 2;                 // bytes per operand element
   const unsigned char* A = reinterpret_cast<const unsigned char*>(Av);
   const unsigned char* Bt = reinterpret_cast<const unsigned char*>(Btv);
@@ -350,6 +350,50 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict_
     }                                                                                             \
     __builtin_amdgcn_wave_barrier();                                                              \
   } while (0)
+  if (pk_epi) {
+    // ---- (bias ->) bf16 outputs (fc1 of a DenseResBlock, `up`, every dgrad): the accumulators are rounded BEFORE the staging.
+    // A lane holds rows r, r+1 (e, e+1) of its column: the pair goes into LDS as ONE dword (v_cvt_pk_bf16_f32), the reader
+    // takes 8 columns x 2 rows with two ds_read_b128, splits the halves with v_perm_b32 and stores two 16-byte row segments:
+    // 16 ds_write_b32 + 4 ds_read_b128 per pass instead of 32 + 8 (same values bit for bit: bias add in fp32, one RNE rounding).
+    constexpr int SLD2 = 68;
+    uint32_t* stage2 = reinterpret_cast<uint32_t*>(smem + w * WAVE_STAGE_BYTES);
+    float bcol[2] = {0.f, 0.f};
+    if (ep.bias) { bcol[0] = ep.bias[n0 + wc * 64 + (lane & 31)]; bcol[1] = ep.bias[n0 + wc * 64 + 32 + (lane & 31)]; }
+    bf16_t* out = ep.out_bf16;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq)
+#pragma unroll
+          for (int e = 0; e < 16; e += 2) {
+            bf16x2_t pr;
+            pr[0] = f2bf(acc[mi][jq][mt][e] + bcol[jq]);
+            pr[1] = f2bf(acc[mi][jq][mt][e + 1] + bcol[jq]);
+            const int p = 2 * kh + ((e & 3) >> 1) + 4 * (e >> 2);                        // row pair inside the 32-row pass
+            stage2[p * SLD2 + jq * 32 + (lane & 31)] = __builtin_bit_cast(uint32_t, pr);
+          }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int p = (lane >> 3) + 8 * i;
+          const uint32_t* sp = stage2 + p * SLD2 + c8;
+          const uint4 lo = *reinterpret_cast<const uint4*>(sp), hi = *reinterpret_cast<const uint4*>(sp + 4);
+          const uint32_t d[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          uint4 r0, r1;
+          r0.x = __builtin_amdgcn_perm(d[1], d[0], 0x05040100u); r1.x = __builtin_amdgcn_perm(d[1], d[0], 0x07060302u);
+          r0.y = __builtin_amdgcn_perm(d[3], d[2], 0x05040100u); r1.y = __builtin_amdgcn_perm(d[3], d[2], 0x07060302u);
+          r0.z = __builtin_amdgcn_perm(d[5], d[4], 0x05040100u); r1.z = __builtin_amdgcn_perm(d[5], d[4], 0x07060302u);
+          r0.w = __builtin_amdgcn_perm(d[7], d[6], 0x05040100u); r1.w = __builtin_amdgcn_perm(d[7], d[6], 0x07060302u);
+          const size_t row = (size_t)(m0 + wr * 128 + mi * 64 + mt * 32 + 2 * p);
+          *reinterpret_cast<uint4*>(out + row * ep.ld_outb + col) = r0;
+          *reinterpret_cast<uint4*>(out + (row + 1) * ep.ld_outb + col) = r1;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    return;
+  }
   if constexpr ((V & 32) != 0) {        // ablation: no epilogue (keep the accumulators alive)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -364,6 +408,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(const void* __restrict_
 }
 
 }  // namespace
+
+// the packed-bf16 epilogue applies: (bias ->) bf16 output and nothing else (knob "gemm_nt256_pk" 0 switches it off: A/B, tests)
+static int nt256_pk_epilogue(const GemmEpilogue& ep) {
+  return (smd_tuning_get("gemm_nt256_pk") != 0 && ep.out_bf16 && !ep.out_f32 && !ep.pre_bf16 && ep.act == SMD_ACT_NONE &&
+          ep.aux_mode == SMD_AUX_NONE && !ep.res_f32 && !ep.res_bf16) ? 1 : 0;
+}
 
 bool gemm_nt256_eligible(int M, int N, int K, const GemmEpilogue& ep, int min_tiles) {
   if (!smd_epi::oct_ok(ep)) return false;
@@ -384,7 +434,8 @@ int launch_gemm_nt256(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M
   const int tiles_m = M / TM, tiles_n = N / TN;
   const int nwg = tiles_m * tiles_n;
   SMD_ARG_CHECK(smd_epi::oct_ok(ep), "gemm_nt256: epilogue not supported (alignment / alpha / res_bf16 / accumulate)");
-#define SMD_NT256_LAUNCH(V_) hipLaunchKernelGGL((gemm_nt256_kernel<V_, false>), dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep, nullptr, nullptr)
+  const int pk = nt256_pk_epilogue(ep);
+#define SMD_NT256_LAUNCH(V_) hipLaunchKernelGGL((gemm_nt256_kernel<V_, false>), dim3(nwg), dim3(512), 0, st, A, lda, Bt, ldb, M, N, K, tiles_n, nwg, ep, nullptr, nullptr, pk)
   // schedule variants 1..3 compute the same result (A/B runs); the ABLATION variants (bits 4, 8, 32, 64: parts of the
   // kernel removed, wrong results by construction) exist only in a -DSMD_ABLATIONS build (tools/kbench.py --gemm-ab)
   switch (smd_tuning_get("gemm_nt256_variant")) {
@@ -420,7 +471,7 @@ int launch_gemm_nt256_fp8(const unsigned char* A8, int lda, const uint32_t* scal
   SMD_ARG_CHECK(ep.out_f32 || ep.out_bf16 || ep.pre_bf16, "gemm_nt256_fp8: no output");
   const int tiles_n = N / TN, nwg = (M / TM) * tiles_n;
   hipLaunchKernelGGL((gemm_nt256_kernel<0, true>), dim3(nwg), dim3(512), 0, st, A8, lda, Bt8, ldb, M, N, K, tiles_n, nwg, ep, scale_a,
-                     scale_b);
+                     scale_b, nt256_pk_epilogue(ep));
   SMD_LAUNCH_CHECK();
   return 0;
 }

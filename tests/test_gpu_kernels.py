@@ -154,6 +154,34 @@ def test_gemm_nt256_matches_128_tiles_and_is_deterministic(L, dev):
         assert torch.equal(o, outs[1])
 
 
+@pytest.mark.parametrize("M,N,K,with_bias", [(256, 256, 128, True), (512, 768, 256, False), (8192, 2048, 2048, True), (8192, 2048, 2048, False)])
+def test_gemm_nt256_packed_bf16_epilogue_is_bitwise_the_staged_one(L, dev, M, N, K, with_bias):
+    """(bias ->) bf16 outputs of the 256x256 kernel (fc1 of a DenseResBlock, `up`, every dgrad: 7 of the 10 launches of a train
+    step) round the accumulators BEFORE the LDS staging and stage row PAIRS as dwords (knob gemm_nt256_pk, default on): half
+    the ds_write / ds_read traffic of the fp32 staging.  Same arithmetic (fp32 bias add, one RNE rounding): bit-identical."""
+    import smd_amd.lib as lib
+    g = torch.Generator().manual_seed(M + N + K + int(with_bias))
+    Ad = bf(torch.randn(M, K, generator=g)).to(dev)
+    Bd = bf(torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bd = torch.randn(N, generator=g).to(dev) if with_bias else None
+    outs = {}
+    lib.check(L.smd_set_tuning(b"gemm_nt256", 2))
+    try:
+        for pk in (1, 0, 1):
+            lib.check(L.smd_set_tuning(b"gemm_nt256_pk", pk))
+            o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+            ck(L, L.smd_gemm_bf16_nt(P(Ad), K, P(Bd), K, M, N, K, P(bd), 0, None, 0, None, 0, P(o), N, st()))
+            torch.cuda.synchronize()
+            outs.setdefault(pk, []).append(o)
+    finally:
+        lib.check(L.smd_set_tuning(b"gemm_nt256", 1))
+        lib.check(L.smd_set_tuning(b"gemm_nt256_pk", 1))
+    ref = Ad.double().cpu() @ Bd.double().cpu().t() + (bd.double().cpu() if with_bias else 0.0)
+    assert bool(torch.isfinite(outs[1][0].float()).all())
+    assert rel(outs[1][0].float(), ref) < 4e-3
+    assert torch.equal(outs[1][0], outs[0][0]), "packed-bf16 epilogue differs from the fp32-staged one"
+    assert torch.equal(outs[1][0], outs[1][1])
+
 
 def test_gemm_nt_rejects_bad_k(L, dev):
     import smd_amd.lib as lib
