@@ -70,6 +70,10 @@ def parse(argv=None):
     ap.add_argument("--dp-buckets", type=int, default=1, help="N > 1 GPUs: chunks per gradient all-reduce stage (GradComm)")
     ap.add_argument("--dp-payload", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1 GPUs: wire format of the gradient all-reduce (bf16 halves the xGMI bytes; off by default)")
+    ap.add_argument("--dp-algorithm", choices=["all_reduce", "rs_ag"], default="all_reduce",
+                    help="N > 1 GPUs: one all_reduce per bucket, or reduce_scatter + all_gather (one direct hop per phase on the xGMI mesh)")
+    ap.add_argument("--dp-layer-buckets", type=int, default=1,
+                    help="N > 1 GPUs: 1 = the stem slice is reduced per encoder layer behind the engine's per-layer gradient events")
     ap.add_argument("--sampler-chains", type=int, default=2, choices=[1, 2],
                     help="graph-replayed sampling as two concurrent half-batch chains (default) or one chain")
     ap.add_argument("--no-roofline-microbench", action="store_true",
@@ -493,7 +497,8 @@ def main():
     for kv in a.tuning:
         k, _, v = kv.partition("=")
         lib.check(lib.get_lib().smd_set_tuning(k.encode(), int(v)))
-    comm = GradComm(buckets=a.dp_buckets, payload=a.dp_payload) if world > 1 else None
+    comm = (GradComm(buckets=a.dp_buckets, payload=a.dp_payload, algorithm=a.dp_algorithm, layer_buckets=bool(a.dp_layer_buckets))
+            if world > 1 else None)
     do_train, do_sample = a.mode in ("both", "train"), a.mode in ("both", "sample")
 
     w = Workload(a, a.config, a.dtype, rank, world, dev, comm)
@@ -562,6 +567,8 @@ def main():
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,
+                       **({"dp": {"algorithm": a.dp_algorithm, "buckets_per_stage": a.dp_buckets, "payload": a.dp_payload,
+                                  "layer_buckets": bool(a.dp_layer_buckets)}} if world > 1 else {}),
                        "sample_step": "eager" if a.no_graph else ("hipGraph replay, 2 concurrent half-batch chains" if nch == 2 else "hipGraph replay"),
                        "rng": a.rng_impl},
             "repeats": a.repeats, "block_values": head["block_values"], "spread": head["spread"],

@@ -78,6 +78,7 @@ int smd_engine_padded_channels(const smd_engine* e);
  *                        (every gradient element is written, not accumulated, by the default kernels)
  *   "nt256_min_tiles" 0  > 0: Dense layers take the 256x256 GEMM from this many output tiles up (default rule: 192)
  *   "fp8_dgrad" 1        fp8 mode, training: the DenseResBlock dgrad GEMMs on e4m3 operands too
+ *   "dp_layer_events" 0  1: per-encoder-layer gradient-complete events in the stem backward (smd_engine_wait_grad_bucket)
  *   "opt_overlap" 0      smd_engine_optimizer_step placement (any time).  Bit 0: the update of the output-stage slice (parameters
  *                        >= smd_engine_head_param_offset, ~75 % of the bytes) runs on the side stream and is NOT complete in
  *                        stream order when the call returns: the next smd_engine_loss_backward of the same handle waits for it
@@ -136,6 +137,14 @@ typedef struct smd_train_hyper {
   float grad_scale;        /* multiplies the gradients first (1/world_size after a SUM all-reduce) */
 } smd_train_hyper;
 int smd_engine_optimizer_step(smd_engine* e, const smd_train_hyper* h, void* stream);
+/* Data-parallel gradient buckets of the stem slice [0, head offset) in BACKWARD order: bucket b = encoder layer L-1-b (the last
+ * bucket also holds in_proj).  With option "dp_layer_events" = 1, smd_engine_loss_backward (stage 2 or 0) records an event per
+ * bucket as soon as its gradients are final; smd_engine_wait_grad_bucket makes `stream` (the communication stream) wait for it,
+ * so the collective of layer l starts while the layers below are still in their backward pass.  The last bucket is final when
+ * the call returns (in the caller's stream order).  (The reference has no counterpart: jax.pmap's pmean at train_ncsn.py:282.) */
+int smd_engine_num_grad_buckets(const smd_engine* e);
+int smd_engine_grad_bucket(const smd_engine* e, int bucket, int64_t* offset, int64_t* length);
+int smd_engine_wait_grad_bucket(smd_engine* e, int bucket, void* stream);
 /* Makes `stream` wait for an output-stage update deferred by "opt_overlap" bit 0 (no-op when none is pending). */
 int smd_engine_join_update(smd_engine* e, void* stream);
 

@@ -99,6 +99,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "fp8") { e->impl.fp8 = value ? 1 : 0; return 0; }
   if (std::string(key) == "fp8_dgrad") { e->impl.fp8_dgrad = value ? 1 : 0; return 0; }
   if (std::string(key) == "opt_overlap") { e->impl.opt_overlap = value & 3; return 0; }
+  if (std::string(key) == "dp_layer_events") { e->impl.dp_layer_events = value ? 1 : 0; return 0; }
   if (std::string(key) == "opt_fused") { e->impl.set_opt_fused(value != 0); return 0; }     // 0: norm / update / re-cast as three passes (A/B)
   if (std::string(key) == "opt_side_blocks") { e->impl.opt_side_blocks = value < 0 ? 0 : value; return 0; }
   if (std::string(key) == "w8_dirty") { e->impl.mark_w8_dirty(); return 0; }   // the bf16 operand pack changed under another handle
@@ -147,6 +148,12 @@ int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes) {
 const float* smd_engine_loss_per_sample(const smd_engine* e) { return e ? e->impl.loss_per_sample() : nullptr; }
 const float* smd_engine_pred(const smd_engine* e) { return e ? e->impl.pred() : nullptr; }
 
+int smd_engine_num_grad_buckets(const smd_engine* e) { return e ? e->impl.num_grad_buckets() : -1; }
+int smd_engine_grad_bucket(const smd_engine* e, int bucket, int64_t* offset, int64_t* length) {
+  NEED(e);
+  return e->impl.grad_bucket(bucket, offset, length);
+}
+int smd_engine_wait_grad_bucket(smd_engine* e, int bucket, void* stream) { NEED(e); return e->impl.wait_grad_bucket(bucket, S(stream)); }
 int smd_engine_join_update(smd_engine* e, void* stream) { NEED(e); return e->impl.join_update(S(stream)); }
 int smd_engine_optimizer_step(smd_engine* e, const smd_train_hyper* h, void* stream) {
   NEED(e);

@@ -110,6 +110,14 @@ class SmdEngine {
   int opt_overlap = 0;
   int opt_side_blocks = 0;              // > 0: workgroups of the deferred output-stage sweep (grid-stride: throttles its HBM rate); 0 = one per tile
   void set_opt_fused(bool on) { opt_fused_user_ = on; }
+  // Data-parallel gradient buckets of the STEM slice in backward order (option "dp_layer_events" = 1): loss_backward(stage 2 / 0)
+  // records one event per encoder layer l = L-1 .. 1 as soon as that layer's parameter gradients are final (its grouped weight
+  // gradients on the side stream + its two LayerNorm reductions), so the caller can start that layer's collective while the
+  // layers below are still in their backward pass; the last bucket (in_proj + layer 0) is final when the call returns.
+  int dp_layer_events = 0;
+  int num_grad_buckets() const { return d_.arch == 0 ? d_.num_layers : 1; }
+  int grad_bucket(int b, int64_t* off, int64_t* len) const;
+  int wait_grad_bucket(int b, hipStream_t s);      // `s` waits for bucket b's event (no-op for the last bucket / events off)
   int join_update(hipStream_t st);      // make `st` wait for a deferred output-stage update (no-op when none is pending)
   int prepare_sampler(hipStream_t st);                       // FiLM tables for every timestep
   int sample_step(const SampleStepIO& io, hipStream_t st);   // eps-net forward + fused reverse step
@@ -233,6 +241,8 @@ class SmdEngine {
   bool head_norm_ready_ = false;               // the head slots of norm_partial hold this step's output-stage partials (side stream)
   bool head_pending_ = false;                  // an output-stage update is in flight on the side stream
   hipEvent_t head_done_ev_ = nullptr;          // recorded behind it (owned; not from the recycled pool)
+  std::vector<hipEvent_t> bucket_ev_;          // dp_layer_events: one per early stem bucket (owned)
+  int buckets_recorded_ = 0;
 
   struct Work {
     // inputs / outputs of the network

@@ -36,6 +36,7 @@ SmdEngine::SmdEngine(const SmdModelDesc& d) : d_(d) { build_layout(); }
 SmdEngine::~SmdEngine() {
   if (side_) (void)hipStreamSynchronize(side_);        // a deferred update may still be reading the caller's buffers
   if (head_done_ev_) (void)hipEventDestroy(head_done_ev_);
+  for (hipEvent_t e : bucket_ev_) (void)hipEventDestroy(e);
   for (hipEvent_t e : events_) (void)hipEventDestroy(e);
   if (side_) (void)hipStreamDestroy(side_);
 }
@@ -411,6 +412,24 @@ int SmdEngine::bind_schedule(const float* coef, const float* sqrt_ap, const floa
                              float* film_tables) {
   SMD_ARG_CHECK(coef && sqrt_ap && alphas_prod_ext, "bind_schedule: null pointer");
   coef_ = coef; sqrt_ap_ = sqrt_ap; alphas_prod_ext_ = alphas_prod_ext; film_tables_ = film_tables;
+  return 0;
+}
+
+int SmdEngine::grad_bucket(int b, int64_t* off, int64_t* len) const {
+  SMD_ARG_CHECK(b >= 0 && b < num_grad_buckets() && off && len, "grad_bucket: index %d of %d", b, num_grad_buckets());
+  if (d_.arch != 0) { *off = 0; *len = head_off_; return 0; }
+  const int L = d_.num_layers, l = L - 1 - b;                  // bucket b = encoder layer L-1-b; the last one also holds in_proj
+  const int64_t lo = l == 0 ? 0 : enc_[l].ln1.g_off;
+  const int64_t hi = l + 1 < L ? enc_[l + 1].ln1.g_off : head_off_;
+  *off = lo; *len = hi - lo;
+  return 0;
+}
+
+int SmdEngine::wait_grad_bucket(int b, hipStream_t s) {
+  SMD_ARG_CHECK(b >= 0 && b < num_grad_buckets(), "wait_grad_bucket: index %d of %d", b, num_grad_buckets());
+  if (b >= buckets_recorded_) return 0;                        // the last bucket, or events off: complete in the caller's stream order
+  hipError_t e = hipStreamWaitEvent(s, bucket_ev_[b], 0);
+  if (e != hipSuccess) { smd_set_error("wait_grad_bucket: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
 }
 
@@ -826,6 +845,7 @@ int SmdEngine::set_debug_snapshots(void* buf, int64_t bytes) {
 }
 
 int SmdEngine::backward_stem(hipStream_t st) {
+  buckets_recorded_ = 0;
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims;
   const int R = rows(), B = batch_;
   // debug snapshots (set_debug_snapshots): segment `seg` of layer l <- src, stream-ordered behind the kernel that wrote it
@@ -897,6 +917,30 @@ int SmdEngine::backward_stem(hipStream_t st) {
     // this layer's four 128-wide wgrads as one side-stream launch; layer 0's wait for in_proj's (the 4-tile in_proj
     // problem alone was a 17 us launch + a reduce of its own at the very end of the step)
     if (group_wgrad == 2 && l > 0) RC(flush_grouped_wgrads(st));
+    if (dp_layer_events && group_wgrad == 2 && l > 0) {
+      // this layer's parameter gradients are final once its two LayerNorm reductions (main stream) and its grouped weight
+      // gradients (side stream) have run: one event behind both
+      RC(flush_ln_reduce(st));
+      const int b = d_.num_layers - 1 - l;
+      while ((int)bucket_ev_.size() <= b) {
+        hipEvent_t ev = nullptr;
+        SMD_ARG_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess, "backward_stem: cannot create an event");
+        bucket_ev_.push_back(ev);
+      }
+      hipStream_t es = st;
+      if (side_wgrad && side_) {
+        hipEvent_t em = take_event();
+        SMD_ARG_CHECK(em, "backward_stem: cannot create an event");
+        hipError_t e = hipEventRecord(em, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side_, em, 0);
+        if (e != hipSuccess) { smd_set_error("backward_stem: event: %s", hipGetErrorString(e)); return (int)e; }
+        es = side_;
+        side_pending_ = true;
+      }
+      hipError_t e = hipEventRecord(bucket_ev_[b], es);
+      if (e != hipSuccess) { smd_set_error("backward_stem: event: %s", hipGetErrorString(e)); return (int)e; }
+      buckets_recorded_ = b + 1;
+    }
   }
   return dense_bwd(in_proj_, W.x_bf16, Cp_, W.dhb[0], E, R, nullptr, 0, nullptr, 0, SMD_AUX_NONE, st, true);
 }

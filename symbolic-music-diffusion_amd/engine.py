@@ -336,6 +336,20 @@ class Engine:
         self._wstate["ver"] += 1            # the step re-casts the operand pack (this handle re-quantises itself)
         self._wseen = self._wstate["ver"]
 
+    # ------------------------------------------------------------------ data-parallel gradient buckets (stem slice)
+    def grad_buckets(self) -> List[Tuple[int, int]]:
+        """(offset, length) of the stem-slice gradient buckets in backward order (include/smd_hip.h)."""
+        out = []
+        for b in range(int(self.L.smd_engine_num_grad_buckets(self.h))):
+            off, ln = C.c_int64(), C.c_int64()
+            _lib.check(self.L.smd_engine_grad_bucket(self.h, b, C.byref(off), C.byref(ln)), "grad_bucket")
+            out.append((off.value, ln.value))
+        return out
+
+    def wait_grad_bucket(self, bucket: int, stream: "torch.cuda.Stream") -> None:
+        """``stream`` waits for the event the stem backward recorded behind bucket ``bucket`` (option dp_layer_events)."""
+        _lib.check(self.L.smd_engine_wait_grad_bucket(self.h, bucket, stream.cuda_stream), "wait_grad_bucket")
+
     def _borrow(self, ptr: int, shape) -> torch.Tensor:
         """View of an engine-internal fp32 buffer inside our workspace tensor."""
         base = self.workspace.data_ptr()

@@ -238,6 +238,10 @@ ENGINE_FLAGS: List[FlagDef] = [
        "bf16 (default: +2 % train throughput; eps_hat parity 5.7e-3 -> 6.3e-3, loss curves indistinguishable over 400 steps, "
        "profiles/r3_trunk_dtype_curves.txt) or fp32 as the reference keeps it.  Logged at start-up and recorded in the "
        "checkpoint metadata; inference always uses bf16.", ("bf16", "fp32")),
+    _D("dp_algorithm", "enum", "all_reduce", "Data-parallel gradient reduction (more than one rank): one all_reduce per bucket, or "
+       "rs_ag = reduce_scatter + all_gather (one direct hop per phase on the 8-GPU xGMI mesh).", ("all_reduce", "rs_ag")),
+    _D("dp_layer_buckets", "bool", True, "Data-parallel: reduce the encoder-stem gradients per layer in backward order, each "
+       "collective started by the engine's per-layer gradient event instead of at the end of the backward pass."),
     _D("synthetic", "bool", False, "Use synthetic latents clip(0.25*N(0,1),-1,1) instead of --dataset."),
     _D("synthetic_examples", "int", 4096, "Synthetic examples per epoch."),
     _D("sample_ema", "bool", False, "sample_ncsn: sample from the EMA weights (reference uses raw weights)."),

@@ -116,10 +116,24 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     if comm is None:
         eng.loss_backward(batch, lab, e, stage=0, **kw)
     else:
+        layered = comm.layer_buckets and batch.is_cuda and eng.head_offset > 0
+        if layered != getattr(eng, "_dp_layer_events", False):
+            eng.set_option("dp_layer_events", int(layered))
+            eng._dp_layer_events = layered
         eng.loss_backward(batch, lab, e, stage=1, **kw)
         comm.reduce_async(eng.grads[eng.head_offset:])          # output-stage gradients are final
         eng.loss_backward(None, None, None, stage=2, **kw)
-        comm.reduce_async(eng.grads[:eng.head_offset])
+        if layered:
+            # the stem slice in backward order, one collective per encoder layer: layer l's starts behind the event the engine
+            # recorded when ITS gradients became final, not behind the whole stem backward; the last bucket (in_proj + layer 0)
+            # waits for the stream as before
+            g = eng.grads
+            buckets = eng.grad_buckets()
+            for b, (off, ln) in enumerate(buckets):
+                early = b + 1 < len(buckets)
+                comm.reduce_async(g[off:off + ln], after=(lambda s, b=b: eng.wait_grad_bucket(b, s)) if early else None)
+        else:
+            comm.reduce_async(eng.grads[:eng.head_offset])
         comm.wait()
     # gradients were scaled by 1/(global_batch*S*C) at the loss, so the all-reduce SUM is the global mean
     eng.optimizer_step(learning_rate, lr_gamma, lr_interval, grad_clip, mu, 1.0)
@@ -145,29 +159,40 @@ def evaluate(dataset, model: Model, sigmas, rng: PRNGKey, continuous_noise: bool
 
 
 class GradComm:
-    """Gradient all-reduce on a side stream (RCCL when the tensors are on GPUs, gloo in the CPU tests); SUM (the loss
-    already carries 1/global_count).
+    """Gradient reduction on a side stream (RCCL when the tensors are on GPUs, gloo in the CPU tests); SUM (the loss
+    already carries 1/global_count).  Every rank ends with bitwise the same reduced gradient in every mode.
 
     ``buckets``: every reduce_async(flat) is cut into this many contiguous chunks, each its own collective, so the ring
     starts moving the first chunk while later ones are still queued (xGMI is point-to-point: a ring all-reduce is
     per-link bound, ~153 GB/s, and a 100 MB fp32 gradient is ~1.3 ms of wire time at 8 ranks however it is cut; smaller
     chunks only shorten the pipeline fill).  ``payload="bf16"``: the chunk is rounded to bf16 into a persistent staging
     buffer, reduced in bf16 and widened back in place -- half the bytes on the links for ~2^-9 relative rounding per
-    addend; off by default because the reference reduces fp32 (jax.lax.pmean, train_ncsn.py:282)."""
+    addend; off by default because the reference reduces fp32 (jax.lax.pmean, train_ncsn.py:282).
+    ``algorithm="rs_ag"``: reduce_scatter + all_gather instead of all_reduce -- on the 8-GPU xGMI mesh every GPU has a direct
+    link to every other, so each of the two phases is ONE hop of n/8 per peer over 7 links in parallel
+    where a ring makes 2 x 7 dependent hops; which one RCCL's own all_reduce picks is its tuning, this makes it a choice.
+    ``layer_buckets``: the stem slice is reduced per encoder layer in backward order, each collective gated by the engine's
+    per-layer gradient event (train_step; engine option dp_layer_events) instead of by the end of the stem backward."""
 
-    def __init__(self, group=None, buckets: int = 1, payload: str = "fp32"):
+    def __init__(self, group=None, buckets: int = 1, payload: str = "fp32", algorithm: str = "all_reduce",
+                 layer_buckets: bool = True):
         import torch.distributed as dist
         if payload not in ("fp32", "bf16"):
             raise ValueError(f"payload must be 'fp32' or 'bf16', got {payload!r}")
+        if algorithm not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"algorithm must be 'all_reduce' or 'rs_ag', got {algorithm!r}")
         self.dist = dist
         self.group = group
         self.world_size = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.buckets = max(1, int(buckets))
         self.payload = payload
+        self.algorithm = algorithm
+        self.layer_buckets = bool(layer_buckets)
         self._works = []
         self._stream = None
         self._stage = {}                    # (data_ptr, numel) -> bf16 staging buffer
+        self._shard = {}                    # (data_ptr, numel, dtype) -> reduce_scatter output shard
         self._pending = []                  # (fp32 chunk, bf16 buffer) to widen after the collective
 
     def _chunks(self, flat: torch.Tensor):
@@ -176,6 +201,25 @@ class GradComm:
         step = -(-step // 1024) * 1024      # 4 KiB-aligned chunk starts
         return [flat[i:min(i + step, n)] for i in range(0, n, step)]
 
+    def _collective(self, buf: torch.Tensor) -> None:
+        """SUM over the ranks of ``buf`` in place, asynchronously (the works are collected in self._works)."""
+        d, W = self.dist, self.world_size
+        if self.algorithm == "all_reduce" or buf.numel() < 2 * W:
+            self._works.append(d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        main = buf.numel() - buf.numel() % W
+        key = (buf.data_ptr(), buf.numel(), buf.dtype)
+        shard = self._shard.get(key)
+        if shard is None:
+            shard = self._shard[key] = torch.empty(main // W, dtype=buf.dtype, device=buf.device)
+        # phase 1: rank r ends with the sum of slice r; phase 2: every rank collects the W reduced slices (identical bytes
+        # everywhere by construction).  The all_gather reads what the reduce_scatter wrote: wait() orders the two (on
+        # GPUs it orders the communication stream, it does not block the host).
+        d.reduce_scatter_tensor(shard, buf[:main], op=d.ReduceOp.SUM, group=self.group, async_op=True).wait()
+        self._works.append(d.all_gather_into_tensor(buf[:main], shard, group=self.group, async_op=True))
+        if main < buf.numel():
+            self._works.append(d.all_reduce(buf[main:], op=d.ReduceOp.SUM, group=self.group, async_op=True))
+
     def _reduce(self, chunk: torch.Tensor) -> None:
         if self.payload == "bf16":
             key = (chunk.data_ptr(), chunk.numel())
@@ -183,18 +227,24 @@ class GradComm:
             if buf is None:
                 buf = self._stage[key] = torch.empty(chunk.numel(), dtype=torch.bfloat16, device=chunk.device)
             buf.copy_(chunk)
-            self._works.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._collective(buf)
             self._pending.append((chunk, buf))
         else:
-            self._works.append(self.dist.all_reduce(chunk, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._collective(chunk)
 
-    def reduce_async(self, flat: torch.Tensor) -> None:
+    def reduce_async(self, flat: torch.Tensor, after=None) -> None:
+        """Start the reduction of ``flat`` on the communication stream.  ``after(stream)``: a callable that makes that stream
+        wait for exactly what ``flat`` depends on (an engine gradient-bucket event); default: everything enqueued on the
+        current stream so far."""
         if self.world_size == 1:
             return
         if flat.is_cuda:
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=flat.device)
-            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+            if after is not None:
+                after(self._stream)
+            else:
+                self._stream.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(self._stream):
                 for c in self._chunks(flat):
                     self._reduce(c)

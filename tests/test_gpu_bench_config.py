@@ -265,6 +265,42 @@ def test_data_parallel_engine_equivalence_single_gpu():
     assert worst < 1e-2
 
 
+def test_stem_gradient_bucket_events_gate_exactly_their_layer():
+    """Data-parallel early start (engine option dp_layer_events, trainer.GradComm(layer_buckets=True)): the stem backward records
+    one event per encoder layer as soon as that layer's gradients are final.  A second stream that waits ONLY for bucket b's
+    event must read the final gradient of that layer -- from a NaN-poisoned buffer, while the layers below are still running."""
+    _, p, model = build("base")
+    x0, labels, eps, _ = draws()
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    eng.set_option("dp_layer_events", 1)
+    buckets = eng.grad_buckets()
+    assert len(buckets) == 6 and buckets[-1][0] == 0 and buckets[0][0] + buckets[0][1] == eng.head_offset
+    assert all(buckets[i + 1][0] + buckets[i + 1][1] == buckets[i][0] for i in range(5))       # backward order, no gaps
+    xd, ld, ed = x0.cuda(), labels.int().cuda(), eps.cuda()
+    comm = torch.cuda.Stream()
+    g = eng.grads
+    for rep in range(3):
+        g.fill_(float("nan"))
+        eng.loss_backward(xd, ld, ed, stage=1)
+        eng.loss_backward(None, None, None, stage=2)
+        snaps = []
+        for b, (off, ln) in enumerate(buckets[:-1]):
+            eng.wait_grad_bucket(b, comm)
+            with torch.cuda.stream(comm):
+                snaps.append(g[off:off + ln].clone())
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(g).all())
+        for (off, ln), snap in zip(buckets[:-1], snaps):
+            assert torch.equal(snap, g[off:off + ln]), "a bucket event fired before its layer's gradients were final"
+    eng.set_option("dp_layer_events", 0)
+    ref = g.clone()
+    eng.loss_backward(xd, ld, ed, stage=0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.grads, ref)                     # the per-layer LayerNorm reductions change nothing in the result
+
+
 @pytest.mark.parametrize("arch,C,B", [("TransformerDDPM", 512, 256), ("TransformerDDPM", 42, 8), ("DenseDDPM", 512, 64),
                                       ("DenseDDPM", 42, 64)])
 def test_every_gradient_element_is_written_without_the_memset(arch, C, B):

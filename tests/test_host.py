@@ -274,6 +274,28 @@ def _dp_worker(rank, world, port, tmp):
     assert lossy.dtype == torch.float32 and 1e-5 < err < 8e-3, err          # bf16 rounding of two addends and of their sum
     with pytest.raises(ValueError):
         GradComm(payload="fp16")
+    with pytest.raises(ValueError):
+        GradComm(algorithm="tree")
+    # reduce_scatter + all_gather instead of all_reduce: the same sums (a tail that does not divide by the world size
+    # included), bitwise the same bytes on every rank, also with per-layer buckets (the `after` gate is a no-op on CPU)
+    for kw in (dict(), dict(buckets=3), dict(payload="bf16")):
+        rs = GradComm(algorithm="rs_ag", **kw)
+        v = grads(slice(rank * half, (rank + 1) * half)).float().clone()
+        n_odd = v.numel() - (1 - v.numel() % 2)                 # an odd length: one element goes through the tail all_reduce
+        v = v[:n_odd].clone()
+        gate_calls = []
+        rs.reduce_async(v[head:], after=None)
+        rs.reduce_async(v[:head], after=lambda s: gate_calls.append(s))
+        rs.wait()
+        if kw.get("payload") == "bf16":
+            assert float((v.double() - full[:n_odd]).norm() / full[:n_odd].norm()) < 8e-3
+        else:
+            assert torch.allclose(v.double(), full[:n_odd], rtol=1e-5, atol=1e-9), (kw, float((v.double() - full[:n_odd]).abs().max()))
+        assert gate_calls == []                                  # CPU tensors: no communication stream to gate
+        mine_bytes = v.clone()
+        other = [torch.empty_like(v) for _ in range(world)]
+        dist.all_gather(other, mine_bytes)
+        assert all(torch.equal(o, mine_bytes) for o in other), f"rs_ag {kw}: ranks hold different reduced gradients"
     flat = torch.full((10,), float(rank))
     comm.broadcast_params(flat)
     assert float(flat.sum()) == 0.0

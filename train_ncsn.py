@@ -85,7 +85,7 @@ def train(FLAGS, train_batches, valid_batches, sigmas, output_dir, rank=0, world
     if rank == 0:
         log.info("training trunk dtype: %s (GEMM operands: %s%s)", FLAGS.trunk_dtype, FLAGS.dtype,
                  "" if FLAGS.dtype != "fp8" else (", e4m3 dgrads" if FLAGS.fp8_dgrad else ", bf16 dgrads"))
-    comm = GradComm() if world > 1 else None
+    comm = GradComm(algorithm=FLAGS.dp_algorithm, layer_buckets=FLAGS.dp_layer_buckets) if world > 1 else None
     if comm is not None:
         comm.broadcast_params(model.params)
         model.engine.refresh_weights()
