@@ -98,8 +98,11 @@ def _noise_embedding_bf16(noise, channels):
     return rb(torch.cat([torch.sin(arg), torch.cos(arg)], dim=1))
 
 
+_EMB_OVERRIDE = None      # (B, film_channels) tensor: the embedding the device kernel produced (see make_model)
+
+
 def _film(P, t, name, film_channels, mlp_dims, sequence):
-    e = _noise_embedding_bf16(t, film_channels)
+    e = _noise_embedding_bf16(t, film_channels) if _EMB_OVERRIDE is None else _EMB_OVERRIDE.to(t.dtype)
     zf = H(e @ P.w(name + ".fc1") + P.b(name + ".fc1"))          # d zf1 = (dp W2^T) swish'(zf1) -> bf16
     e = rb(O.swish(zf))
     e = H(rb(e @ P.w(name + ".fc2") + P.b(name + ".fc2")))       # dp -> bf16
@@ -161,16 +164,21 @@ def dense_ddpm(p, cfg, inputs, t):
     return H(ao @ P.w("out_proj") + P.b("out_proj"))
 
 
-def make_model(p, cfg, backward=False):
+def make_model(p, cfg, backward=False, noise_embedding=None):
     """model(x, cond) -> eps_hat as the bf16 engine computes it, up to fp32 accumulation order (float64 arithmetic).
-    backward=True: parameters with requires_grad get the engine's gradient (bf16 gradient storage emulated by hooks)."""
+    backward=True: parameters with requires_grad get the engine's gradient (bf16 gradient storage emulated by hooks).
+    noise_embedding: the (B, 128) sinusoidal embedding as the device kernel produced it (smd_noise_embed).  Its angles
+    reach 5000 rad in float32 (models/ncsn.py:36-38 computes them in float32 too), where ONE ulp of the frequency moves the
+    sine by 3e-4: whichever float32 exp / sincos evaluates it, a few per cent of the bf16 entries land on the other side of
+    a rounding boundary, and every FiLM scale / shift moves with them.  Passing the device's own embedding takes that
+    library-level ambiguity out of the comparison."""
     fn = dense_ddpm if cfg.architecture == "DenseDDPM" else transformer_ddpm
 
     def model(x, t):
-        global _BACKWARD
-        _BACKWARD = bool(backward)
+        global _BACKWARD, _EMB_OVERRIDE
+        _BACKWARD, _EMB_OVERRIDE = bool(backward), noise_embedding
         try:
             return fn(p, cfg, x, t)
         finally:
-            _BACKWARD = False
+            _BACKWARD, _EMB_OVERRIDE = False, None
     return model
