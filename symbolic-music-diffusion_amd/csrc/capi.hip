@@ -145,6 +145,14 @@ int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes) {
   NEED(e);
   return e->impl.set_debug_snapshots(buf, bytes);
 }
+int smd_engine_debug_tensor(const smd_engine* e, const char* name, int index, const void** ptr, int64_t* rows, int64_t* cols,
+                            int32_t* dtype) {
+  NEED(e);
+  int dt = 0;
+  const int rc = e->impl.debug_tensor(name, index, ptr, rows, cols, &dt);
+  if (rc == 0 && dtype) *dtype = dt;
+  return rc;
+}
 const float* smd_engine_loss_per_sample(const smd_engine* e) { return e ? e->impl.loss_per_sample() : nullptr; }
 const float* smd_engine_pred(const smd_engine* e) { return e ? e->impl.pred() : nullptr; }
 

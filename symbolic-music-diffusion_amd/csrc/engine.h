@@ -150,6 +150,10 @@ class SmdEngine {
   // identical steps can be compared kernel by kernel.  bytes >= debug_snapshot_bytes(); null switches it off.
   int64_t debug_snapshot_bytes() const { return (int64_t)d_.num_layers * 34 * rows() * d_.embed_channels; }
   int set_debug_snapshots(void* buf, int64_t bytes);
+  // Debugging aid (tests/test_gpu_engine.py layer-by-layer check): device pointer, shape and element type (0 fp32, 1 bf16) of
+  // an activation the TRAINING forward pass saved in the bound workspace -- "x_bf16", "h"[l], "h_mid"[l], "a1"[l], "qkv"[l],
+  // "o"[l], "a2"[l], "h_last", "af", "y"[k], "ya1"[k], "o1"[k], "ya2"[k], "emb", "f1"[k], "p"[k], "ss"[k], "ao", "pred", "s".
+  int debug_tensor(const char* name, int index, const void** ptr, int64_t* rows, int64_t* cols, int* dtype) const;
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   // The 2048-wide trunk y (models/ncsn.py:171-176) lives in bf16 instead of fp32: the residual operand and the output of
   // every fc2 GEMM and the LayerNorm inputs (forward and backward) shrink by half (-64 MB per DenseResBlock; the fp32

@@ -844,6 +844,38 @@ int SmdEngine::set_debug_snapshots(void* buf, int64_t bytes) {
   return 0;
 }
 
+int SmdEngine::debug_tensor(const char* name, int index, const void** ptr, int64_t* rows_out, int64_t* cols_out, int* dtype) const {
+  SMD_ARG_CHECK(name && ptr && rows_out && cols_out && dtype, "debug_tensor: null argument");
+  SMD_ARG_CHECK(batch_ > 0 && training_, "debug_tensor: bind a training workspace first");
+  const int64_t R = rows(), B = batch_, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
+  const int L = d_.arch == 0 ? d_.num_layers : 0, K = nblocks();
+  const std::string n(name);
+  auto set = [&](const void* p, int64_t r, int64_t c, int dt) { *ptr = p; *rows_out = r; *cols_out = c; *dtype = dt; return 0; };
+  auto layer = [&](int hi) { return index >= 0 && index < hi; };
+  if (n == "x_bf16") return set(W.x_bf16, R, Cp_, 1);
+  if (n == "pred") return set(W.pred, R, d_.data_channels, 0);
+  if (n == "s") return set(W.s, B, 1, 0);
+  if (n == "emb") return set(W.emb, B, F, 1);
+  if (n == "ao") return set(W.ao, R, M, 1);
+  if (n == "af" && L > 0) return set(W.af, R, E, 1);
+  if (n == "h_last" && L > 0) return set(W.h_last, R, E, 0);
+  if (n == "h" && layer(L)) return set(W.h[index], R, E, 0);
+  if (n == "h_mid" && layer(L)) return set(W.h_mid[index], R, E, 0);
+  if (n == "a1" && layer(L)) return set(W.a1[index], R, E, 1);
+  if (n == "qkv" && layer(L)) return set(W.qkv[index], R, 3 * E, 1);
+  if (n == "o" && layer(L)) return set(W.o[index], R, E, 1);
+  if (n == "a2" && layer(L)) return set(W.a2[index], R, E, 1);
+  if (n == "y" && layer(K + 1)) return set(W.y[index], R, M, trunk_bf16_on() ? 1 : 0);
+  if (n == "ya1" && layer(K)) return set(W.ya1[index], R, M, 1);
+  if (n == "o1" && layer(K)) return set(W.o1[index], R, M, 1);
+  if (n == "ya2" && layer(K)) return set(W.ya2[index], R, M, 1);
+  if (n == "f1" && layer(K)) return set(W.f1[index], B, 4 * F, 1);
+  if (n == "p" && layer(K)) return set(W.p[index], B, 4 * F, 1);
+  if (n == "ss" && layer(K)) return set(W.ss[index], B, 2 * M, 0);
+  smd_set_error("debug_tensor: unknown tensor '%s'[%d]", name, index);
+  return -1;
+}
+
 int SmdEngine::backward_stem(hipStream_t st) {
   buckets_recorded_ = 0;
   const int S = d_.seq_len, E = d_.embed_channels, M = d_.mlp_dims;

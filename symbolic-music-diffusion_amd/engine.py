@@ -358,6 +358,19 @@ class Engine:
         assert 0 <= off and off + 4 * n <= self.workspace.numel()
         return self.workspace[off:off + 4 * n].view(torch.float32).view(*shape)
 
+    def debug_tensor(self, name: str, index: int = 0) -> torch.Tensor:
+        """A saved activation of the last training-mode forward pass (include/smd_hip.h smd_engine_debug_tensor): a view into
+        the workspace, fp32 or bf16."""
+        ptr, r, c, dt = C.c_void_p(), C.c_int64(), C.c_int64(), C.c_int32()
+        _lib.check(self.L.smd_engine_debug_tensor(self.h, name.encode(), int(index), C.byref(ptr), C.byref(r), C.byref(c), C.byref(dt)),
+                   "debug_tensor")
+        size = 2 if dt.value == 1 else 4
+        off = ptr.value - self.workspace.data_ptr()
+        n = r.value * c.value
+        assert 0 <= off and off + size * n <= self.workspace.numel()
+        raw = self.workspace[off:off + size * n]
+        return raw.view(torch.bfloat16 if dt.value == 1 else torch.float32).view(r.value, c.value)
+
     def loss_per_sample(self) -> torch.Tensor:
         return self._borrow(self.L.smd_engine_loss_per_sample(self.h), (self.batch,))
 

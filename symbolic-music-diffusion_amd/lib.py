@@ -88,6 +88,8 @@ _SIGS = {
     "smd_engine_pred": (c_void, [c_void]),
     "smd_engine_optimizer_step": (C.c_int, [c_void, C.POINTER(TrainHyper), c_void]),
     "smd_engine_join_update": (C.c_int, [c_void, c_void]),
+    "smd_engine_debug_tensor": (C.c_int, [c_void, C.c_char_p, C.c_int, C.POINTER(c_void), C.POINTER(c_i64), C.POINTER(c_i64),
+                                          C.POINTER(c_i32)]),
     "smd_engine_num_grad_buckets": (C.c_int, [c_void]),
     "smd_engine_grad_bucket": (C.c_int, [c_void, C.c_int, C.POINTER(c_i64), C.POINTER(c_i64)]),
     "smd_engine_wait_grad_bucket": (C.c_int, [c_void, C.c_int, c_void]),
