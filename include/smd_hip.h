@@ -233,14 +233,16 @@ int smd_set_timestep(int32_t* t_ptr, int32_t t, void* stream);
  *               2 (default) = the four-buffer kernel (+ loader waves), unpadded: small-LDS workgroups of the main stream may
  *               share its CU (bitwise repeatable: 0 of 1499 repeated steps differ); 1 = the same kernels
  *               padded to the CU's whole LDS so that nothing shares their CU (the round-2 default, 2 % slower);
- *               0 = the two-buffer kernel, unpadded -- kept for the A/B only: with it on their CU the 128-wide LayerNorm
- *               backward kernels intermittently read a stale register in lanes 48..63 (not repeatable);
+ *               0 = the two-buffer kernel, unpadded: NOT IN THE SHIPPED LIBRARY (the launch fails) -- with it on their CU the
+ *               128-wide LayerNorm backward kernels intermittently compute a wrong row statistic (tools/rsq_repro.hip); it and
+ *               the other experiment instantiations exist in a -DSMD_TN_EXPERIMENTS build only;
  * "tn_mode":    0 (default) = as "tn_exclusive_cu" says; NS*100 + NW*10 + pad picks buffers / issuing waves / pad (0 none,
- *               1 whole CU, 2 96 KiB) of that kernel explicitly (tools/r3_det_modes.sh);
+ *               1 whole CU, 2 96 KiB) of that kernel explicitly; anything but 48x needs the experiment build;
  * "gemm_tn256": 1 = 2048-wide weight gradients use the 256x256 8-phase kernel (default), 0 = 128-wide tiles,
  *               2 = also on small grids (tests);
  * "tn_split_model": 1 = split-K of the 128-wide weight gradients chosen for whole rounds of 256 workgroups;
- * "tn128_loader_waves": 1 = the CU-exclusive 128-wide weight-gradient kernel runs four extra waves that only issue LDS-DMA;
+ * "tn128_loader_waves": 1 = the 128-wide weight-gradient kernel runs four extra waves that only issue LDS-DMA (0 needs the
+ *               experiment build);
  * further keys ("ln_bwd_wide", "ln_fwd_wide", "ln_bwd_narrow", "gemm_nt_deep", "gemm_nt_kg", "mlp_variant", ...) select
  * between equivalent kernels for A/B runs; unknown keys return < 0. */
 int smd_set_tuning(const char* key, int value);

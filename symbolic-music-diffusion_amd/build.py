@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
-SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "attention.hip", "encoder_fused.hip", "diffusion.hip", "rng_jax.hip", "optim.hip",
+SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "ln128.hip", "attention.hip", "encoder_fused.hip", "diffusion.hip", "rng_jax.hip", "optim.hip",
            "engine.hip", "capi.hip"]
 HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h", "rng_threefry.h",
            os.path.join("..", "..", "include", "smd_hip.h")]
@@ -35,6 +35,16 @@ LIB_PATH = os.path.join(CSRC, f"libsmd_hip{_SUFFIX}.so")
 EXTRA_FLAGS = {"encoder_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
                # jax.random streams: every mul/add rounds separately (HIP's __fmul_rn/__fadd_rn are plain operators)
                "rng_jax.hip": ["-ffp-contract=off"]}
+# NO PACKED-FP32 VALU ARITHMETIC in the small-LDS kernels -- LayerNorms, elementwise, optimiser (SMD_SLP=1 in the environment
+# restores hipcc's default for A/B runs).  tools/rsq_repro.hip: a v_pk_mul_f32 that the SLP vectoriser
+# forms on a register pair reads a STALE source in lanes 48..63 when the VALU instruction that wrote that register is two
+# instructions ahead of it and a two-buffer weight-gradient workgroup shares the CU -- with a transcendental or a plain FMA as
+# the producer alike; the same statement as two v_mul_f32 is never wrong.  Per-kernel times are unchanged (profiles/r4k_*).
+# encoder_fused.hip keeps the default: its workgroups take 136-160 KiB of LDS, no GEMM workgroup can join them on a CU, and
+# its GELU phases are 3 % faster with the packed forms.
+if os.environ.get("SMD_SLP") != "1":
+    for _f in ("norm.hip", "ln128.hip", "diffusion.hip", "optim.hip", "attention.hip"):
+        EXTRA_FLAGS.setdefault(_f, []).append("-fno-slp-vectorize")
 
 
 def find_hipcc() -> str:

@@ -751,7 +751,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_narrow128_kernel(LnBwdDev a
       r[it][0] = t0.x; r[it][1] = t0.y; r[it][2] = t0.z; r[it][3] = t0.w; r[it][4] = t1.x; r[it][5] = t1.y; r[it][6] = t1.z; r[it][7] = t1.w;
     }
   }
-  smd_load_settle();
   // all-reduce over the 16 lanes of a row: four xor exchanges (__shfl_xor = ds_bpermute); every step adds two commuting
   // operands, so all 16 lanes end with the bitwise identical sum.  Until round 3 these were DPP row operations
   // (quad_perm / row_half_mirror / row_mirror), suspected of the co-residency miscompare while it was being hunted; the

@@ -47,52 +47,22 @@ __device__ __forceinline__ int smd_clamp_t(int t, int T) { return t < 0 ? 0 : (t
 __device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
 __device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }
 
-// Load-settle fence.  Placed between a kernel's up-front global loads and their first use: every load
-// has returned (vmcnt(0)) and SMD_LOAD_SETTLE x 16 further idle issue cycles have passed before any VALU instruction reads
-// a loaded register.  -1 = no fence (the compiler's counted vmcnt waits directly in front of the first use).
-#ifndef SMD_LOAD_SETTLE
-#define SMD_LOAD_SETTLE -1
-#endif
-__device__ __forceinline__ void smd_load_settle() {
-#if SMD_LOAD_SETTLE >= 0
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int k = 0; k < SMD_LOAD_SETTLE; ++k) asm volatile("s_nop 15" ::: "memory");
-#endif
-}
-
-// LayerNorm 1/sqrt(var + eps) as the bare v_rsq_f32 (the argument is >= 1e-6, never a denormal: same bits as rsqrtf) with
-// EIGHT IDLE ISSUE CYCLES IN FRONT of it (default form, 98).  Round 3 found (profiles/r3_det_root_cause.txt):
-// with a two-buffer weight-gradient workgroup on the same CU, a v_rsq_f32 issued directly behind the VALU instruction that
-// writes its source operand -- what hipcc schedules -- intermittently reads the STALE register in lanes 48..63 (whole rows
-// of the 128-wide LayerNorm backward wrong by ~1e-2 with bit-identical inputs; 99 of 99 repeated steps differ).  Idle cycles
-// behind the instruction do not help (24 of 39), in front of it they do (0 of 499 on the encoder backward).
-// Other values are the experiment builds of that hunt: 0 rsqrtf(), -1 bare v_rsq_f32, N in 1..89 s_nop N-1 behind it, 90 + n
-// s_nop n in front, 99 s_nop 7 on both sides.
-#ifndef SMD_TRANS_SETTLE
-#define SMD_TRANS_SETTLE 98
-#endif
+// LayerNorm 1/sqrt(var + eps): v_rsq_f32 (the argument is >= 1e-6, never a denormal: same bits as rsqrtf) behind eight idle
+// issue cycles.  History: round 3 attributed the intermittently wrong row statistics of the 128-wide
+// LayerNorm backward next to a two-buffer weight-gradient workgroup to this instruction and put the idle cycles in front of
+// it, which lowered the rate without closing it.  The stand-alone reproducer of round 4 (tools/rsq_repro.hip) shows the value
+// this instruction WRITES is always right; what reads a stale register in lanes 48..63 is the v_pk_mul_f32 that hipcc's SLP
+// vectoriser forms for the first use of the result -- with a plain FMA as the producer alike.  The cure is in the build
+// (no packed-fp32 arithmetic in the small-LDS kernels, build.py) and in the library (only the four-buffer weight-gradient
+// kernel ships); the idle cycles stay as they are part of the code every determinism soak has run on.
+// -DSMD_LN_RSTD_BARE (tools/build_rsq_repro.sh): the bare instruction, for the reproducer's victim build.
 __device__ __forceinline__ float smd_ln_rstd(float v) {
-#if SMD_TRANS_SETTLE == 99
-  float r;                 // idle issue cycles on BOTH sides of the transcendental instruction
-  asm volatile("s_nop 7\n\tv_rsq_f32 %0, %1\n\ts_nop 7" : "=v"(r) : "v"(v));
-  return r;
-#elif SMD_TRANS_SETTLE >= 90 && SMD_TRANS_SETTLE <= 97
-  float r;                 // 90 + n: s_nop n in front, nothing behind
-  asm volatile("s_nop %2\n\tv_rsq_f32 %0, %1" : "=v"(r) : "v"(v), "n"(SMD_TRANS_SETTLE - 90));
-  return r;
-#elif SMD_TRANS_SETTLE == 98
-  float r;                 // idle issue cycles only in FRONT of it (its source operand was just written)
-  asm volatile("s_nop 7\n\tv_rsq_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(v));
-  return r;
-#elif SMD_TRANS_SETTLE > 0
-  float r = __builtin_amdgcn_rsqf(v);
-  asm volatile("s_nop %1" : "+v"(r) : "n"(SMD_TRANS_SETTLE - 1));
-  return r;
-#elif SMD_TRANS_SETTLE < 0
+#ifdef SMD_LN_RSTD_BARE
   return __builtin_amdgcn_rsqf(v);
 #else
-  return rsqrtf(v);
+  float r;
+  asm volatile("s_nop 7\n\tv_rsq_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(v));
+  return r;
 #endif
 }
 
