@@ -172,6 +172,9 @@ typedef struct smd_sample_io {
   const uint32_t* tf_infill_keys;
   int64_t tf_n_total;
   int32_t tf_t0;
+  /* Philox key in DEVICE memory ([2] words: seed_lo, seed_hi), NULL = the seed_lo / seed_hi fields above.  A captured
+   * step that reads its key here (and its timestep from t_ptr) can be replayed for a later sampling run with another rng. */
+  const uint32_t* key_ptr;
 } smd_sample_io;
 int smd_engine_prepare_sampler(smd_engine* e, void* stream);
 int smd_engine_init_state(smd_engine* e, float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset,

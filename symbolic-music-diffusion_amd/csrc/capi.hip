@@ -189,6 +189,7 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
   s.infill_z_in = io->infill_z_in; s.metrics_partial = io->metrics_partial; s.collection = io->collection;
   s.slot_table = io->slot_table;
   s.tf_noise_keys = io->tf_noise_keys; s.tf_infill_keys = io->tf_infill_keys; s.tf_n_total = io->tf_n_total; s.tf_t0 = io->tf_t0;
+  s.key_ptr = io->key_ptr;
   return e->impl.sample_step(s, S(stream));
 }
 

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
   const uint32_t bglob = (uint32_t)b + a.sample_offset;
   const size_t sample_base = (size_t)b * a.S * a.C;
   const uint64_t tf_base = (uint64_t)bglob * a.S * a.C;       // this sample's first element in the global jax array
+  const uint32_t key_lo = a.key_ptr ? a.key_ptr[0] : a.key.seed_lo, key_hi = a.key_ptr ? a.key_ptr[1] : a.key.seed_hi;
   TfKey tf_nk{0, 0}, tf_ik{0, 0};
   if (a.tf_noise_keys) { tf_nk.k0 = a.tf_noise_keys[2 * (a.tf_t0 - t)]; tf_nk.k1 = a.tf_noise_keys[2 * (a.tf_t0 - t) + 1]; }
   if (a.tf_infill_keys) { tf_ik.k0 = a.tf_infill_keys[2 * (a.tf_t0 - t)]; tf_ik.k1 = a.tf_infill_keys[2 * (a.tf_t0 - t) + 1]; }
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
           for (int v = 0; v < VEC; ++v) z[v] = jax_normal_from_bits(jax_bits_at(tf_nk, tf_base + e + v, (uint64_t)a.tf_n_total));
         } else {
           const float4 n4 = philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_Z, (uint32_t)t,
-                                           a.key.seed_lo, a.key.seed_hi);
+                                           key_lo, key_hi);
           if constexpr (VEC == 4) { z[0] = n4.x; z[1] = n4.y; z[2] = n4.z; z[3] = n4.w; }
           else z[0] = pick4(n4, e & 3);
         }
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(128 * RG) void reverse_step_kernel(ReverseStepArgs 
             for (int v = 0; v < VEC; ++v) iz[v] = jax_normal_from_bits(jax_bits_at(tf_ik, tf_base + e + v, (uint64_t)a.tf_n_total));
           } else {
             const float4 n4 = philox_normal4((uint32_t)(e >> 2), bglob, SMD_STREAM_INFILL, (uint32_t)t,
-                                             a.key.seed_lo, a.key.seed_hi);
+                                             key_lo, key_hi);
             if constexpr (VEC == 4) { iz[0] = n4.x; iz[1] = n4.y; iz[2] = n4.z; iz[3] = n4.w; }
             else iz[0] = pick4(n4, e & 3);
           }

@@ -60,6 +60,7 @@ struct SampleStepIO {
   const uint32_t* tf_infill_keys = nullptr;
   int64_t tf_n_total = 0;
   int tf_t0 = 0;
+  const uint32_t* key_ptr = nullptr;         // device-resident Philox key (overrides seed_lo / seed_hi)
 };
 
 class SmdEngine {

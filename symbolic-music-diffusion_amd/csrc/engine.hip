@@ -1148,6 +1148,7 @@ int SmdEngine::sample_step(const SampleStepIO& io, hipStream_t st) {
   a.sample_offset = io.sample_offset;
   a.infill_samples = io.infill_samples; a.infill_masks = io.infill_masks; a.infill_z_in = io.infill_z_in;
   a.tf_noise_keys = io.tf_noise_keys; a.tf_infill_keys = io.tf_infill_keys; a.tf_n_total = io.tf_n_total; a.tf_t0 = io.tf_t0;
+  a.key_ptr = io.key_ptr;
   a.x_bf16 = W.x_bf16; a.metrics_partial = io.metrics_partial; a.collection = io.collection;
   a.slot_table = io.slot_table;
   a.t_advance = io.t_ptr; a.arrive = W.step_arrive;      // *t_ptr -= 1 by the step's last workgroup (no launch of its own)

@@ -244,6 +244,7 @@ struct ReverseStepArgs {
   unsigned* arrive = nullptr;         // arrival counter for t_advance: zero before the first launch, reset by the kernel
   const float* z_in = nullptr;        // explicit N(0,1) draw [B][S][C] or null -> Philox
   RngKey key{0, 0};
+  const uint32_t* key_ptr = nullptr;  // device-resident key [2] (overrides `key`: a captured step serves later runs with other seeds)
   uint32_t sample_offset = 0;
   const float* infill_samples = nullptr;  // [B][S][C] or null
   const float* infill_masks = nullptr;

@@ -40,7 +40,7 @@ class SampleIO(C.Structure):
                 ("sample_offset", c_u32), ("infill_samples", c_void), ("infill_masks", c_void),
                 ("infill_z_in", c_void), ("metrics_partial", c_void), ("collection", c_void),
                 ("slot_table", c_void), ("tf_noise_keys", c_void), ("tf_infill_keys", c_void), ("tf_n_total", c_i64),
-                ("tf_t0", c_i32)]
+                ("tf_t0", c_i32), ("key_ptr", c_void)]
 
 
 class LangevinIO(C.Structure):
