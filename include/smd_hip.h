@@ -323,6 +323,10 @@ int64_t smd_gemm_tn_slab_elems(void);
 int smd_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const float* beta,
                       const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample,
                       int swish, smd_bf16* out, void* stream);
+/* the engine's form: the input row as fp32 (x) or bf16 (x_bf16: the 2048-wide trunk), exactly one of them non-NULL */
+int smd_layernorm_fwd_ex(const float* x, const smd_bf16* x_bf16, int rows, int D, const float* gamma, const float* beta,
+                         const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample, int swish,
+                         smd_bf16* out, void* stream);
 int smd_layernorm_bwd(const float* x, int rows, int D, const float* gamma, const float* beta,
                       const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample,
                       int swish, const smd_bf16* dout, float* dx, float* dgamma, float* dbeta, float* dscale,

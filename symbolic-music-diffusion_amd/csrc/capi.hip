@@ -282,6 +282,15 @@ int smd_layernorm_fwd(const float* x, int rows, int D, const float* gamma, const
   a.ld_film = ld_film; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.swish = swish; a.out = B(out);
   return launch_layernorm_fwd(a, S(stream));
 }
+int smd_layernorm_fwd_ex(const float* x, const smd_bf16* x_bf16, int rows, int D, const float* gamma, const float* beta,
+                         const float* film_scale, const float* film_shift, int ld_film, int rows_per_sample, int swish, smd_bf16* out,
+                         void* stream) {
+  LnArgs a;
+  a.x = x; a.x_bf16 = B(x_bf16); a.rows = rows; a.D = D; a.gamma = gamma; a.beta = beta; a.film_scale = film_scale;
+  a.film_shift = film_shift; a.ld_film = ld_film; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.swish = swish;
+  a.out = B(out);
+  return launch_layernorm_fwd(a, S(stream));
+}
 int smd_layernorm_bwd(const float* x, int rows, int D, const float* gamma, const float* beta, const float* film_scale,
                       const float* film_shift, int ld_film, int rows_per_sample, int swish, const smd_bf16* dout,
                       float* dx, float* dgamma, float* dbeta, float* dscale, float* dshift, float* partial,

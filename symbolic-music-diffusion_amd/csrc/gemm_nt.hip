@@ -236,7 +236,7 @@ void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N
 // process-wide kernel-selection knobs (smd_set_tuning in the C-ABI)
 namespace {
 struct Knob { const char* key; int value; };
-Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_nt256_pk", 1}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 2}, {"gemm_nt_kg", 1}, {"mlp_hs_dbg", 0}, {"ln_excl", 0}, {"tn_exclusive_cu", 2}, {"tn_split_model", 1}, {"tn128_loader_waves", 1}, {"tn_mode", 0}};
+Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_nt256_pk", 1}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 3}, {"gemm_nt_kg", 1}, {"mlp_hs_dbg", 0}, {"ln_excl", 0}, {"tn_exclusive_cu", 2}, {"tn_split_model", 1}, {"tn128_loader_waves", 1}, {"tn_mode", 0}};
 }
 int smd_tuning_set(const char* key, int value) {
   for (Knob& k : g_knobs)

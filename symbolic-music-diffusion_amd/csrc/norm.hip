@@ -149,7 +149,7 @@ template <int D, bool XBF> struct WideRow {
 // (SGPR row bases, all of a row's loads issued up front).  FS: FiLM + swish (ResBlock norms) or neither.
 // F8: also (or only) write the row as e4m3 with a per-row E8M0 scale (the A operand of the e4m3 GEMM); the row's outputs
 // then wait in registers for the row maximum.
-template <int D, bool XBF, bool FS, int NW, bool F8 = false>
+template <int D, bool XBF, bool FS, int NW, bool F8 = false, bool PF = false>
 __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, int group_rows) {
   typedef RowLayout<D> L;
   constexpr int NV = L::NV;
@@ -170,14 +170,26 @@ __global__ __launch_bounds__(64 * NW) void layernorm_fwd_wide_kernel(LnArgs a, i
   }
   __syncthreads();
   const uint32_t l4 = lane * 4;
-  for (int row = r_begin + w; row < r_end; row += NW) {
-    WideRow<D, XBF> b;                       // dy unused here
+  auto load_row_raw = [&](int row, WideRow<D, XBF>& b) {
     const float* xr = a.x + (size_t)row * D;
     const bf16_t* xbr = a.x_bf16 + (size_t)row * D;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       if constexpr (XBF) b.xb[k] = *reinterpret_cast<const bf16x4_t*>(xbr + (l4 + k * 256));
       else b.xf[k] = *reinterpret_cast<const float4*>(xr + (l4 + k * 256));
+    }
+  };
+  // PF: the NEXT row of this wave is requested before the current one is reduced (a bf16 row is 16 registers): twice the
+  // bytes in flight per wave, the row's arithmetic runs under the next row's HBM latency
+  WideRow<D, XBF> nxt;
+  if constexpr (PF) { if (r_begin + w < r_end) load_row_raw(r_begin + w, nxt); }
+  for (int row = r_begin + w; row < r_end; row += NW) {
+    WideRow<D, XBF> b;                       // dy unused here
+    if constexpr (PF) {
+      b = nxt;
+      if (row + NW < r_end) load_row_raw(row + NW, nxt);
+    } else {
+      load_row_raw(row, b);
     }
     float s = 0.f, sq = 0.f;
 #pragma unroll
@@ -899,9 +911,11 @@ template <int D> static void run_fwd(const LnArgs& a, hipStream_t st) {
       const int ng = (a.rows + gr - 1) / gr;
 #define SMD_FW(XB, FS_)                                                                                               \
   do {                                                                                                               \
-    if (a.out_f8 && smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16, true>), dim3(ng), dim3(1024), 0, st, a, gr); \
+    if (a.out_f8 && smd_tuning_get("ln_fwd_wide") == 3) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16, true, true>), dim3(ng), dim3(1024), 0, st, a, gr); \
+    else if (a.out_f8 && smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16, true>), dim3(ng), dim3(1024), 0, st, a, gr); \
     else if (a.out_f8) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 8, true>), dim3(ng), dim3(512), 0, st, a, gr);       \
     else if (smd_tuning_get("ln_fwd_wide") == 2) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16>), dim3(ng), dim3(1024), 0, st, a, gr); \
+    else if (smd_tuning_get("ln_fwd_wide") == 3) hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 16, false, true>), dim3(ng), dim3(1024), 0, st, a, gr); \
     else hipLaunchKernelGGL((layernorm_fwd_wide_kernel<D, XB, FS_, 8>), dim3(ng), dim3(512), 0, st, a, gr);            \
   } while (0)
       if (a.x_bf16) { if (fs) SMD_FW(true, true); else SMD_FW(true, false); }

@@ -122,6 +122,8 @@ _SIGS = {
     "smd_gemm_tn_slab_elems": (c_i64, []),
     "smd_layernorm_fwd": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int,
                                     C.c_int, c_void, c_void]),
+    "smd_layernorm_fwd_ex": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int,
+                                       C.c_int, c_void, c_void]),
     "smd_layernorm_bwd": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, C.c_int, C.c_int,
                                     C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void, c_i64, c_void]),
     "smd_layernorm_bwd_ex": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, c_void,
