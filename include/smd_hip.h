@@ -80,7 +80,7 @@ int smd_engine_padded_channels(const smd_engine* e);
  *   "fp8_dgrad" 1        fp8 mode, training: the DenseResBlock dgrad GEMMs on e4m3 operands too
  *   "dp_layer_events" 0  1: per-encoder-layer gradient-complete events in the stem backward (smd_engine_wait_grad_bucket)
  *   "opt_overlap" 0      smd_engine_optimizer_step placement (any time).  Bit 0: the update of the output-stage slice (parameters
- *                        >= smd_engine_head_param_offset, ~75 % of the bytes) runs on the side stream and is NOT complete in
+ *                        >= smd_engine_head_param_offset, 86 % of the bytes) runs on the side stream and is NOT complete in
  *                        stream order when the call returns: the next smd_engine_loss_backward of the same handle waits for it
  *                        right before its first output-stage kernel; any other reader of params / m / v / ema / wpack (another
  *                        handle on the same buffers, a host copy) calls smd_engine_join_update(handle, its stream) first.

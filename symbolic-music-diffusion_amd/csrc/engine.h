@@ -100,7 +100,7 @@ class SmdEngine {
                     uint32_t sample_offset, float inv_global_count, int stage, hipStream_t st);
   int optimizer_step(const TrainHyper& h, hipStream_t st);
   // Optimiser placement (optimizer_step is ONE sweep -- clip + Adam + EMA + bf16 re-cast -- in every mode):
-  //   bit 0  the update of the OUTPUT-STAGE slice (parameters >= head_param_offset: ~75 % of the bytes, not needed before the
+  //   bit 0  the update of the OUTPUT-STAGE slice (parameters >= head_param_offset: 86 % of the bytes, not needed before the
   //          `up` projection of the next forward pass) runs on the engine's side stream behind the stem slice's norm; the next
   //          run_network() of THIS handle waits for it right before the first output-stage kernel, every other reader of the
   //          parameters / Adam state / operand pack (another handle, the host, a checkpoint) must call join_update() first;

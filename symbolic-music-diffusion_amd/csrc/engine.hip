@@ -1087,7 +1087,7 @@ int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {
   RC(launch_adam_recast(a, W.opt_consts, wpack_, opt_stem_, st));
   w8_dirty_ = true;
   if ((opt_overlap & 1) && side_wgrad && side_ && opt_head_.total_blocks) {
-    // the output stage's 75 % of the bytes: on the side stream, underneath the next forward pass's encoder
+    // the output stage's 86 % of the bytes: on the side stream, underneath the next forward pass's encoder
     hipEvent_t ev = take_event();
     if (!head_done_ev_ && hipEventCreateWithFlags(&head_done_ev_, hipEventDisableTiming) != hipSuccess) head_done_ev_ = nullptr;
     SMD_ARG_CHECK(ev && head_done_ev_, "optimizer_step: cannot create an event");

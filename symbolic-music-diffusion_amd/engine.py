@@ -53,7 +53,7 @@ def _stream() -> int:
 
 def _joined(name: str) -> property:
     """Buffer attribute whose READ first orders the current stream behind a deferred output-stage optimiser update (any
-    handle on the same parameters): ``opt_overlap`` lets the 75 % of the update that the next forward pass does not need
+    handle on the same parameters): ``opt_overlap`` lets the 86 % of the update that the next forward pass does not need
     until its `up` projection run on the engine's side stream, so everything that looks at the parameters, the Adam state,
     the EMA or the operand pack through Python -- another handle, a checkpoint, a test -- joins here."""
     def get(self):
