@@ -726,6 +726,10 @@ struct MlpHsBwdArgs {
   int rows;
 };
 
+// REGF: the wave's a2 / dh B fragments (its two samples x its token half: 16 x 16 bytes per lane) are read from LDS ONCE and
+// kept in registers for all 16 chunks (the kernel needs 88 registers of the 256 two waves per SIMD may take) instead of being
+// re-read every chunk: 16 of a chunk's ~32 ds_read_b128 and their latency in front of the first MFMA chain are gone.
+template <bool REGF>
 __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[HB_SMEM];
   constexpr int NS = HB_NS, SPW = NS / 2;
@@ -780,6 +784,24 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
     const int arow = (ht * 16 + j) * 256;                               // A row of S1 / S2
     const int tswz = (tok >> 2) & 3;
     const int srow = tid >> 2, spc = tid & 3;                           // store mapping: (token row of the group, 16-B piece)
+    bf16x8_t a2f[REGF ? SPW : 1][4], dhf[REGF ? SPW : 1][4];
+    if constexpr (REGF) {
+      // the bias window + the a2 / dh tiles have landed (what may still fly: the 3 + 3 DMAs of chunks 0 and 1)
+      if (nchunks > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sl = 0; sl < SPW; ++sl) {
+        const int s = sp * SPW + sl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int co = ((ks * 4 + g) ^ (tok & 15)) << 4;
+          a2f[sl][ks] = *reinterpret_cast<lds_b128_ptr>(L + HB_A2 + (s * 32 + tok) * 256 + co);
+          dhf[sl][ks] = *reinterpret_cast<lds_b128_ptr>(L + HB_DH + (s * 32 + tok) * 256 + co);
+        }
+      }
+    }
     for (int c = 0; c < nchunks; ++c) {
       const int buf = c % 3;
       // chunk c has landed; what may still be in flight behind it: chunk c+1 (3 DMAs) and the previous iteration's two
@@ -813,9 +835,13 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
           lds_byte_ptr ta = L + HB_A2 + (s * 32 + tok) * 256, td = L + HB_DH + (s * 32 + tok) * 256;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
-            const int co = ((ks * 4 + g) ^ (tok & 15)) << 4;
-            const bf16x8_t fa = *reinterpret_cast<lds_b128_ptr>(ta + co);
-            const bf16x8_t fd = *reinterpret_cast<lds_b128_ptr>(td + co);
+            bf16x8_t fa, fd;
+            if constexpr (REGF) { fa = a2f[sl][ks]; fd = dhf[sl][ks]; }
+            else {
+              const int co = ((ks * 4 + g) ^ (tok & 15)) << 4;
+              fa = *reinterpret_cast<lds_b128_ptr>(ta + co);
+              fd = *reinterpret_cast<lds_b128_ptr>(td + co);
+            }
             z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], fa, z, 0, 0, 0);
             du = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[ks], fd, du, 0, 0, 0);
           }
@@ -1556,7 +1582,8 @@ int launch_mlp_block_bwd_hs(const bf16_t* a2, const bf16_t* dh, int rows, const 
                 "mlp_block_bwd_hs: rows=%d must be a multiple of 128 and the hidden width %d a multiple of 512 (<= 8192)", rows, M);
   MlpHsBwdArgs a;
   a.a2 = a2; a.dh = dh; a.W1t = W1t; a.W2 = W2; a.W1 = W1; a.b1 = b1; a.M = M; a.u = u; a.dz = dz; a.part = part; a.rows = rows;
-  hipLaunchKernelGGL(mlp_hs_bwd_kernel, dim3((rows / (S_TOK * HB_NS)) * HS_NQ), dim3(512), 0, st, a);
+  if (smd_tuning_get("mlp_variant") == 9) hipLaunchKernelGGL(mlp_hs_bwd_kernel<false>, dim3((rows / (S_TOK * HB_NS)) * HS_NQ), dim3(512), 0, st, a);   // A/B: fragments re-read per chunk
+  else hipLaunchKernelGGL(mlp_hs_bwd_kernel<true>, dim3((rows / (S_TOK * HB_NS)) * HS_NQ), dim3(512), 0, st, a);
   SMD_LAUNCH_CHECK();
   return 0;
 }
