@@ -207,6 +207,41 @@ def test_library_exports_every_declared_symbol():
     assert set(lib._SIGS) == set(names)
 
 
+def test_gradient_buckets_cover_the_stem_in_backward_order():
+    """Host-only part of the data-parallel interface (include/smd_hip.h smd_engine_grad_bucket): the buckets of the stem
+    slice are the encoder layers from the last to the first, contiguous, the last one also holding in_proj, and together they are
+    exactly [0, head_param_offset) -- checked against the oracle's parameter layout (no GPU: layout functions only)."""
+    import ctypes as C
+    import smd_amd.lib as lib
+    L = lib.get_lib()
+    for kw in (dict(num_layers=6, num_heads=8, num_mlp_layers=2), dict(num_layers=8, num_heads=16, num_mlp_layers=3)):
+        cfg = O.NetConfig(data_channels=512, **kw)
+        d = lib.ModelDesc(0, 512, 32, kw["num_layers"], kw["num_heads"], kw["num_mlp_layers"], 2048, 128, 128, 1000)
+        h = C.c_void_p()
+        lib.check(L.smd_engine_create(C.byref(d), C.byref(h)))
+        try:
+            head = int(L.smd_engine_head_param_offset(h))
+            sizes = {}
+            for name, shape in O.param_spec(cfg):
+                key = name.split(".")[1] if name.startswith("enc.") else name.split(".")[0]
+                sizes[key] = sizes.get(key, 0) + int(np.prod(shape))
+            nb = int(L.smd_engine_num_grad_buckets(h))
+            assert nb == kw["num_layers"]
+            end = head
+            for b in range(nb):
+                off, ln = C.c_int64(), C.c_int64()
+                lib.check(L.smd_engine_grad_bucket(h, b, C.byref(off), C.byref(ln)))
+                layer = kw["num_layers"] - 1 - b
+                want = sizes[str(layer)] + (sizes["in_proj"] if layer == 0 else 0)
+                assert off.value + ln.value == end and ln.value == want, (b, off.value, ln.value, want)
+                end = off.value
+            assert end == 0
+            with pytest.raises(ValueError):
+                lib.check(L.smd_engine_grad_bucket(h, nb, C.byref(off), C.byref(ln)))
+        finally:
+            L.smd_engine_destroy(h)
+
+
 def test_product_never_imports_oracle():
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "symbolic-music-diffusion_amd")
     import re
