@@ -86,7 +86,9 @@ int smd_engine_padded_channels(const smd_engine* e);
  *                        handle on the same buffers, a host copy) calls smd_engine_join_update(handle, its stream) first.
  *                        Bit 1: smd_engine_loss_backward(stage 0) reduces that slice's gradient-norm partials on the side
  *                        stream under the encoder backward; the caller must not change the gradient before the optimiser step
- *                        (leave it off around an all-reduce).  The Python host sets 3 (1 with a communicator). */
+ *                        (leave it off around an all-reduce).  Opt-in (the Python host leaves 0 unless SMD_OPT_OVERLAP is set): +1 % at best on a
+ *                        process's first training handle, and bit 0 halved the step rate of later handles of the same process
+ *                        (DESIGN.md section 6). */
 int smd_engine_set_option(smd_engine* e, const char* key, int value);
 
 int smd_engine_bind_params(smd_engine* e, float* params, smd_bf16* wpack);

@@ -142,7 +142,8 @@ class Engine:
 
     def set_opt_overlap(self, value: int) -> None:
         """Engine option "opt_overlap" (include/smd_hip.h): bit 0 defers the output-stage update to the side stream, bit 1
-        reduces that slice's norm partials early.  SMD_OPT_OVERLAP in the environment overrides (A/B runs)."""
+        reduces that slice's norm partials early.  SMD_OPT_OVERLAP in the environment overrides (A/B runs; the trainer's default
+        is 0: DESIGN.md section 6)."""
         value = int(os.environ.get("SMD_OPT_OVERLAP", value))
         if value != self._opt_overlap:
             self.set_option("opt_overlap", value)

@@ -110,9 +110,12 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
                                             global_batch=gb)
     kw = dict(seed=rng.seed, sample_offset=sample_offset, global_batch=gb, used_alphas=ua, continuous_noise=continuous_noise,
               objective="dsm" if dsm else "ddpm")
-    # optimiser placement (engine option "opt_overlap"): the output-stage slice of the update runs on the engine's side stream
-    # underneath the next step's encoder forward; without a communicator that slice's norm partials are reduced early too
-    eng.set_opt_overlap(3 if comm is None else 1)
+    # optimiser placement (engine option "opt_overlap"): 0 = the whole sweep on this stream.  Deferring the
+    # output-stage slice to the side stream (bit 0) measured +1 % at best on a process's FIRST training engine and HALVED the
+    # step rate of every second later engine of the same process (profiles/r4q_extras_opt_overlap.txt: the per-step
+    # main-waits-on-side / side-waits-on-main pattern on whatever hardware queue the new side stream is mapped to), so it is
+    # opt-in: SMD_OPT_OVERLAP=3 (1 with a communicator).
+    eng.set_opt_overlap(0)
     if comm is None:
         eng.loss_backward(batch, lab, e, stage=0, **kw)
     else:
