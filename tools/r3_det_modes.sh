@@ -1,4 +1,6 @@
 #!/bin/bash
+# HISTORICAL (round 3): needs a -DSMD_TN_EXPERIMENTS build for every tn_mode but 48x since round 4 (tools/build_rsq_repro.sh);
+# the engine-free form of this matrix is tools/rsq_repro.
 # wgrad-kernel variants against the co-residency non-repeatability (tn_mode = NS*100 + NW*10 + pad code), library suffix $1
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}

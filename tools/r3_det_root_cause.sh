@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (round 3): the SMD_TRANS_SETTLE / SMD_LOAD_SETTLE library variants this script compares were removed in round 4 --
+# the instruction-level cause they were probing was refuted by tools/rsq_repro.hip; kept as the record of
+# how profiles/r3_det_root_cause.txt was produced.  The engine-free reproducer is tools/build_rsq_repro.sh + tools/rsq_repro.
 # Round-3 root-cause matrix for the co-residency non-repeatability.  Run on the GPU box from the repo root:
 #   tools/r3_det_root_cause.sh <tag>   -> gpurun_out/<tag>_det.txt
 # Libraries: default; _ts2 / _ts8 = SMD_TRANS_SETTLE 2 / 8 (bare v_rsq_f32 + s_nop 1 / 7 before its first consumer in every
