@@ -240,10 +240,16 @@ class Workload:
                          lr_gamma=0.98, lr_interval=10000, sample_offset=self.rank * self.B, global_batch=self.B * self.world)
 
     def _reset_t(self):
+        """Restart the walk: t = 999 AND a fresh N(0,1) state, as a new diffusion_dynamics call would (the step time depends
+        on the data: replaying t = 999 ... on a finished sample runs a few per cent faster than a real walk)."""
         torch = self.torch
         import smd_amd.lib as lib
-        for ch in self.chains:       # the engine's own one-thread kernel on the chain's stream (no framework fill on the replay stream)
+        self.restarts = getattr(self, "restarts", 0) + 1
+        hB = self.B // self.nchains
+        for c, ch in enumerate(self.chains):   # the engine's own kernels on the chain's stream (no framework fill on the replay stream)
             st = ch["stream"] if ch["stream"] is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(st):
+                ch["eng"].init_state(ch["x"], 4321 + self.restarts, self.rank * self.B + c * hB)
             lib.check(lib.get_lib().smd_set_timestep(ch["t_ptr"].data_ptr(), 999, st.cuda_stream))
         self.walked = 0
 
