@@ -130,7 +130,9 @@ int64_t smd_engine_debug_snapshot_bytes(const smd_engine* e);
 int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes);
 /* Debugging aid (layer-by-layer parity): device pointer, shape and element type (0 fp32, 1 bf16) of an activation the training
  * forward pass saved in the bound workspace: "x_bf16", "h"/"h_mid"/"a1"/"qkv"/"o"/"a2" [encoder layer], "h_last", "af",
- * "y" [0..K], "ya1"/"o1"/"ya2"/"f1"/"p"/"ss" [block], "emb", "ao", "pred", "s".  Valid until the next call on the handle. */
+ * "y" [0..K], "ya1"/"o1"/"ya2"/"f1"/"p"/"ss" [block], "emb", "ao", "pred", "s"; and of the last backward pass the operands of
+ * every weight-gradient GEMM: "dpred", "dyb" [0..K], "do1"/"dss_bf16"/"dp"/"df1" [block], "dhb" [0..2L], "dqkv"/"dz1"/"u" [encoder
+ * layer].  Valid until the next call on the handle. */
 int smd_engine_debug_tensor(const smd_engine* e, const char* name, int index, const void** ptr, int64_t* rows, int64_t* cols,
                             int32_t* dtype);
 const float* smd_engine_loss_per_sample(const smd_engine* e);   /* [B] device pointer */

@@ -153,7 +153,9 @@ class SmdEngine {
   int set_debug_snapshots(void* buf, int64_t bytes);
   // Debugging aid (tests/test_gpu_engine.py layer-by-layer check): device pointer, shape and element type (0 fp32, 1 bf16) of
   // an activation the TRAINING forward pass saved in the bound workspace -- "x_bf16", "h"[l], "h_mid"[l], "a1"[l], "qkv"[l],
-  // "o"[l], "a2"[l], "h_last", "af", "y"[k], "ya1"[k], "o1"[k], "ya2"[k], "emb", "f1"[k], "p"[k], "ss"[k], "ao", "pred", "s".
+  // "o"[l], "a2"[l], "h_last", "af", "y"[k], "ya1"[k], "o1"[k], "ya2"[k], "emb", "f1"[k], "p"[k], "ss"[k], "ao", "pred", "s"; the
+  // operands of the weight-gradient GEMMs of the last backward pass: "dpred", "dyb"[k], "do1"[k], "dss_bf16"[k], "dp"[k], "df1"[k],
+  // "dhb"[i], "dqkv"[l], "dz1"[l], "u"[l].
   int debug_tensor(const char* name, int index, const void** ptr, int64_t* rows, int64_t* cols, int* dtype) const;
   int film_side = 1;                                          // FiLM-generator wgrads deferred to the side stream too
   // The 2048-wide trunk y (models/ncsn.py:171-176) lives in bf16 instead of fp32: the residual operand and the output of

@@ -872,6 +872,18 @@ int SmdEngine::debug_tensor(const char* name, int index, const void** ptr, int64
   if (n == "f1" && layer(K)) return set(W.f1[index], B, 4 * F, 1);
   if (n == "p" && layer(K)) return set(W.p[index], B, 4 * F, 1);
   if (n == "ss" && layer(K)) return set(W.ss[index], B, 2 * M, 0);
+  // gradient activations of the last loss_backward: every dY / X operand of a weight-gradient GEMM has its own slot (the side
+  // stream reads them late), so each weight gradient can be re-derived from exactly the operands the engine used
+  if (n == "dpred") return set(W.dpred, R, Cp_, 1);
+  if (n == "dyb" && layer(K + 1)) return set(W.dyb[index], R, M, 1);
+  if (n == "do1" && layer(K)) return set(W.do1[index], R, M, 1);
+  if (n == "dss_bf16" && layer(K)) return set(W.dss_bf16[index], B, 2 * M, 1);
+  if (n == "dp" && layer(K)) return set(W.dp[index], B, 4 * F, 1);
+  if (n == "df1" && layer(K)) return set(W.df1[index], B, 4 * F, 1);
+  if (n == "dhb" && layer(2 * L + 1)) return set(W.dhb[index], R, E, 1);
+  if (n == "dqkv" && layer(L)) return set(W.dqkv[index], R, 3 * E, 1);
+  if (n == "dz1" && layer(L)) return set(W.dz1[index], R, M, 1);
+  if (n == "u" && layer(L)) return set(W.u[index], R, M, 1);
   smd_set_error("debug_tensor: unknown tensor '%s'[%d]", name, index);
   return -1;
 }

@@ -324,6 +324,45 @@ def test_saved_activations_layer_by_layer(arch, C, L, H, K, B):
           + ", ".join(f"{n} {e:.1e} ({f * 100:.2f} %)" for n, (e, f) in worst.items()))
 
 
+@pytest.mark.parametrize("C,L,H,K,B,dtype", [(512, 6, 8, 2, 256, "bf16"), (146, 2, 16, 3, 8, "bf16"), (512, 6, 8, 2, 256, "fp8")])
+def test_every_weight_gradient_from_its_saved_operands(C, L, H, K, B, dtype):
+    """train_ncsn.py:282-283 "gradients must be the gradients", teacher-forced and in situ: every Dense kernel / bias gradient
+    of a training step against float64 X^T dY / colsum(dY) of exactly the operands the engine's weight-gradient GEMM read (the
+    saved activation X and the gradient activation dY, both bf16, each in its own workspace slot: smd_engine_debug_tensor).
+    No rounding between the operands and the result but the fp32 accumulation over 8192 token rows: 1e-5 -- for the grouped
+    128-wide launches with their slab reduces, the four-problem 256 x 256 launch, the bias rows of the ones-MFMA, the ragged
+    in_proj / out_proj of C = 146, and the e4m3 mode (whose weight gradients stay bf16)."""
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    cfg = NetConfig(architecture="TransformerDDPM", data_channels=C, seq_len=32, num_layers=L, num_heads=H, num_mlp_layers=K,
+                    num_timesteps=1000, dtype=dtype)
+    model = N.Model(cfg, "cuda:0", seed=2)
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    x0, g = data(B, (32, C))
+    eng.grads.fill_(float("nan"))
+    eng.loss_backward(x0.cuda(), None, None, seed=17, stage=0)
+    torch.cuda.synchronize()
+    gv = eng.named_views(eng.grads)
+    T = lambda name, i=0: eng.debug_tensor(name, i).double()          # on the device: 8192 x 2048 x 2048 products in float64
+    pairs = [("out_proj", T("ao"), T("dpred")[:, :C]), ("up", T("af"), T("dyb", 0)), ("in_proj", T("x_bf16")[:, :C], T("dhb", 0))]
+    for k in range(K):
+        pairs += [(f"res.{k}.fc2", T("ya2", k), T("dyb", k + 1)), (f"res.{k}.fc1", T("ya1", k), T("do1", k)),
+                  (f"film.{k}.ss", T("p", k), T("dss_bf16", k)), (f"film.{k}.fc2", T("f1", k), T("dp", k)), (f"film.{k}.fc1", T("emb"), T("df1", k))]
+    for l in range(L):
+        pairs += [(f"enc.{l}.mlp.fc2", T("u", l), T("dhb", 2 * l + 2)), (f"enc.{l}.mlp.fc1", T("a2", l), T("dz1", l)),
+                  (f"enc.{l}.attn.out", T("o", l), T("dhb", 2 * l + 1)), (f"enc.{l}.attn.qkv", T("a1", l), T("dqkv", l))]
+    worst = (0.0, "")
+    for name, X, dY in pairs:
+        eW = rel(gv[name + ".kernel"], (X.t() @ dY).cpu())
+        eb = rel(gv[name + ".bias"], dY.sum(0).cpu())
+        worst = max(worst, (eW, name + ".kernel"), (eb, name + ".bias"))
+        assert eW < 1e-5 and eb < 1e-5, f"{name}: dW rel {eW:.2e}, db rel {eb:.2e}"
+    assert len(pairs) == 3 + 5 * K + 4 * L
+    print(f"C={C} L={L} K={K} B={B} {dtype}: {2 * len(pairs)} weight / bias gradients vs float64 of their saved operands, worst {worst[1]} {worst[0]:.2e}")
+
+
 def test_optimizer_step_matches_oracle():
     ocfg, p, model = make(C=42, L=2, K=1)
     B = 4
