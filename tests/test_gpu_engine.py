@@ -361,6 +361,41 @@ def test_every_weight_gradient_from_its_saved_operands(C, L, H, K, B, dtype):
         assert eW < 1e-5 and eb < 1e-5, f"{name}: dW rel {eW:.2e}, db rel {eb:.2e}"
     assert len(pairs) == 3 + 5 * K + 4 * L
     print(f"C={C} L={L} K={K} B={B} {dtype}: {2 * len(pairs)} weight / bias gradients vs float64 of their saved operands, worst {worst[1]} {worst[0]:.2e}")
+    # ---- the two fused encoder backward kernels whose inputs AND outputs all persist, teacher-forced the same way (bf16
+    # outputs: one rounding stage, flips next to ties): mlp_hs_bwd (recomputed u = gelu(z), dz = (dh W2^T) gelu'(z)) and
+    # attn_block_bwd (dq | dk | dv from the saved q k v and dh_mid)
+    import bf16_emulation as E
+    rb = E.rb
+    pv = {k: v.double() for k, v in eng.named_views(eng.params).items()}
+    Wb = lambda name: rb(pv[name + ".kernel"])
+    d = 128 // H
+    worst_e = (0.0, "")
+    for l in range(L):
+        pre = f"enc.{l}"
+        a2, dh_in = T("a2", l), T("dhb", 2 * l + 2)
+        z = (a2 @ Wb(pre + ".mlp.fc1") + pv[pre + ".mlp.fc1.bias"]).requires_grad_(True)
+        u_ref = O.gelu(z)
+        (gp,) = torch.autograd.grad(u_ref.sum(), z)
+        dz_ref = rb((dh_in @ Wb(pre + ".mlp.fc2").t()) * gp)
+        for name, got, want in (("u", T("u", l), rb(u_ref.detach())), ("dz1", T("dz1", l), dz_ref)):
+            e = rel(got, want)
+            worst_e = max(worst_e, (e, f"{name}[{l}]"))
+            assert e < 2e-4, f"{name}[{l}]: rel {e:.2e}"
+        qkv, dh_mid = T("qkv", l), T("dhb", 2 * l + 1)
+        q, k, v = (t_.reshape(B, 32, H, d) for t_ in qkv.split(128, dim=-1))
+        dO = rb(dh_mid @ Wb(pre + ".attn.out").t()).reshape(B, 32, H, d)
+        sc = 1.0 / d ** 0.5
+        p_ = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q, k) * sc, dim=-1)
+        dP = torch.einsum("bqhd,bkhd->bhqk", dO, v)
+        dS = rb(p_ * (dP - (p_ * dP).sum(-1, keepdim=True)))
+        dq = rb(torch.einsum("bhqk,bkhd->bqhd", dS, k) * sc)
+        dk = rb(torch.einsum("bhqk,bqhd->bkhd", dS, q) * sc)
+        dv = rb(torch.einsum("bhqk,bqhd->bkhd", rb(p_), dO))
+        want = torch.cat([t_.reshape(B * 32, 128) for t_ in (dq, dk, dv)], dim=1)
+        e = rel(T("dqkv", l), want)
+        worst_e = max(worst_e, (e, f"dqkv[{l}]"))
+        assert e < 2e-4, f"dqkv[{l}]: rel {e:.2e}"
+    print(f"   fused encoder backward kernels vs float64 of their saved inputs (bf16 outputs): worst {worst_e[1]} {worst_e[0]:.2e}")
 
 
 def test_optimizer_step_matches_oracle():
