@@ -398,6 +398,95 @@ def test_every_weight_gradient_from_its_saved_operands(C, L, H, K, B, dtype):
     print(f"   fused encoder backward kernels vs float64 of their saved inputs (bf16 outputs): worst {worst_e[1]} {worst_e[0]:.2e}")
 
 
+@pytest.mark.parametrize("C,L,H,B", [(512, 6, 8, 256), (146, 2, 16, 8)])
+def test_encoder_backward_chain_from_snapshots(C, L, H, B):
+    """The rest of the encoder backward, teacher-forced: the shared per-layer gradient buffers (da2 partial tiles, dh behind
+    each LayerNorm backward, dA_E) are copied out behind every kernel (smd_engine_debug_snapshots), so each kernel's output can
+    be re-derived in float64 from exactly its inputs: da2 = dz W1^T (sum of the four partial tiles), the LayerNorm-2 backward
+    on those tiles + the residual gradient (ln128_bwd_parts: fp32 dh and its bf16 copy), da1 = dqkv Wqkv^T (the tail of
+    attn_block_bwd), the LayerNorm-1 backward (layernorm_bwd_narrow128), and the four LayerNorm parameter gradients of the layer.
+    fp32 outputs 1e-5, bf16 outputs 2e-4.  Together with test_every_weight_gradient_from_its_saved_operands every kernel of the
+    encoder backward is pinned in situ, at B = 256."""
+    import bf16_emulation as E
+    import smd_amd.lib as lib
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    cfg = NetConfig(architecture="TransformerDDPM", data_channels=C, seq_len=32, num_layers=L, num_heads=H, num_mlp_layers=2, num_timesteps=1000)
+    model = N.Model(cfg, "cuda:0", seed=4)
+    g = torch.Generator().manual_seed(3)
+    for k_, v_ in model.engine.named_views().items():           # non-trivial LayerNorm affine
+        if k_.endswith(".scale"):
+            v_.copy_((1 + 0.1 * torch.randn(v_.shape, generator=g)).cuda())
+    model.engine.refresh_weights()
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    Lc = lib.get_lib()
+    nbytes = int(Lc.smd_engine_debug_snapshot_bytes(eng.h))
+    snap = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    lib.check(Lc.smd_engine_debug_snapshots(eng.h, snap.data_ptr(), nbytes))
+    x0, _ = data(B, (32, C))
+    try:
+        eng.loss_backward(x0.cuda(), None, None, seed=23, stage=0)
+        torch.cuda.synchronize()
+    finally:
+        lib.check(Lc.smd_engine_debug_snapshots(eng.h, None, 0))
+    R, RE = B * 32, B * 32 * 128
+    SEG = {"parts": (0, 16, torch.float32), "dh_ln2": (16, 4, torch.float32), "dA_E": (20, 2, torch.bfloat16), "dh_ln1": (22, 4, torch.float32),
+           "dh_in": (26, 4, torch.float32), "h_mid": (30, 4, torch.float32)}
+
+    def seg(l, name):
+        off, ln, dt = SEG[name]
+        slot = L - 1 - l                                          # slots are filled in execution order: last layer first
+        return snap[(slot * 34 + off) * RE:(slot * 34 + off + ln) * RE].view(dt).double()
+
+    T = lambda name, i=0: eng.debug_tensor(name, i).double()
+    pv = {k: v.double() for k, v in eng.named_views(eng.params).items()}
+    gv = eng.named_views(eng.grads)
+    rb = E.rb
+
+    def ln_bwd(x, dy, gamma):
+        mean = x.mean(-1, keepdim=True)
+        rstd = torch.rsqrt((x * x).mean(-1, keepdim=True) - mean * mean + 1e-6)
+        xh = (x - mean) * rstd
+        dxh = dy * gamma
+        dx = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+        return dx, (dy * xh).sum(0), dy.sum(0)
+
+    worst = {}
+
+    def check(name, got, want, tol):
+        e = rel(got, want)
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert e < tol, f"{name}: rel {e:.2e}"
+
+    for l in range(L):
+        pre = f"enc.{l}"
+        parts = seg(l, "parts").view(4, R, 128)
+        da2 = (parts[0] + parts[1]) + (parts[2] + parts[3])
+        check("da2 = dz W1^T", da2, T("dz1", l) @ rb(pv[pre + ".mlp.fc1.kernel"]).t(), 1e-5)
+        h_mid = T("h_mid", l)
+        assert torch.equal(seg(l, "h_mid").view(R, 128), h_mid)
+        dx, dg, db = ln_bwd(h_mid, da2, pv[pre + ".ln2.scale"])
+        dh2 = dx + seg(l, "dh_in").view(R, 128)
+        check("ln2 backward -> dh (fp32)", seg(l, "dh_ln2").view(R, 128), dh2, 1e-5)
+        check("ln2 backward -> dh (bf16 copy)", T("dhb", 2 * l + 1), rb(dh2), 2e-4)
+        check("ln2 dgamma", gv[pre + ".ln2.scale"], dg.cpu(), 1e-5)
+        check("ln2 dbeta", gv[pre + ".ln2.bias"], db.cpu(), 1e-5)
+        dA = seg(l, "dA_E").view(R, 128)
+        check("da1 = dqkv Wqkv^T (bf16)", dA, rb(T("dqkv", l) @ rb(pv[pre + ".attn.qkv.kernel"]).t()), 2e-4)
+        dx, dg, db = ln_bwd(T("h", l), dA, pv[pre + ".ln1.scale"])
+        dh1 = dx + seg(l, "dh_ln2").view(R, 128)
+        check("ln1 backward -> dh (fp32)", seg(l, "dh_ln1").view(R, 128), dh1, 1e-5)
+        check("ln1 backward -> dh (bf16 copy)", T("dhb", 2 * l), rb(dh1), 2e-4)
+        check("ln1 dgamma", gv[pre + ".ln1.scale"], dg.cpu(), 1e-5)
+        check("ln1 dbeta", gv[pre + ".ln1.bias"], db.cpu(), 1e-5)
+        if l + 1 < L:                                             # the dh that enters layer l is what layer l + 1's ln1 backward left
+            assert torch.equal(seg(l, "dh_in"), seg(l + 1, "dh_ln1"))
+    print(f"C={C} L={L} H={H} B={B}: encoder backward chain vs float64 of each kernel's own inputs: "
+          + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+
+
 def test_optimizer_step_matches_oracle():
     ocfg, p, model = make(C=42, L=2, K=1)
     B = 4
