@@ -125,13 +125,15 @@ int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labe
 int smd_engine_set_used_alphas(smd_engine* e, const float* used_alphas);
 /* Debugging aid (tools/det_first_diff.py): with a buffer of smd_engine_debug_snapshot_bytes() bytes set, the encoder backward
  * copies the shared per-layer gradient buffers (da2 partial tiles, dh, dA_E, dh) behind each of its kernels into it, so two
- * identical steps can be compared kernel by kernel; NULL switches it off (the default). */
+ * identical steps can be compared kernel by kernel; behind those 34 * rows * E bytes per encoder layer follow 2 K + 1 copies of
+ * the output stage's shared dX buffer (bf16 [rows][mlp_dims]; behind out_proj's dgrad, then for block K-1 .. 0 behind the dgrad
+ * of its second and its first Dense).  NULL switches it off (the default). */
 int64_t smd_engine_debug_snapshot_bytes(const smd_engine* e);
 int smd_engine_debug_snapshots(smd_engine* e, void* buf, int64_t bytes);
 /* Debugging aid (layer-by-layer parity): device pointer, shape and element type (0 fp32, 1 bf16) of an activation the training
  * forward pass saved in the bound workspace: "x_bf16", "h"/"h_mid"/"a1"/"qkv"/"o"/"a2" [encoder layer], "h_last", "af",
  * "y" [0..K], "ya1"/"o1"/"ya2"/"f1"/"p"/"ss" [block], "emb", "ao", "pred", "s"; and of the last backward pass the operands of
- * every weight-gradient GEMM: "dpred", "dyb" [0..K], "do1"/"dss_bf16"/"dp"/"df1" [block], "dhb" [0..2L], "dqkv"/"dz1"/"u" [encoder
+ * every weight-gradient GEMM: "dpred", "dyb" [0..K], "do1"/"dss"/"dss_bf16"/"dp"/"df1"/"zf1" [block], "dhb" [0..2L], "dqkv"/"dz1"/"u" [encoder
  * layer].  Valid until the next call on the handle. */
 int smd_engine_debug_tensor(const smd_engine* e, const char* name, int index, const void** ptr, int64_t* rows, int64_t* cols,
                             int32_t* dtype);

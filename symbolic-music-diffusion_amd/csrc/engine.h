@@ -149,7 +149,11 @@ class SmdEngine {
   // tiles after mlp_hs_bwd, dh after the ln2 backward, dA_E after attn_block_bwd, dh after the ln1 backward; plus the layer's
   // incoming dh and its saved h_mid), so that two
   // identical steps can be compared kernel by kernel.  bytes >= debug_snapshot_bytes(); null switches it off.
-  int64_t debug_snapshot_bytes() const { return (int64_t)d_.num_layers * 34 * rows() * d_.embed_channels; }
+  // layout: the encoder's per-layer segments (34 * rows * E bytes a layer, last layer first), then 2 K + 1 copies of the output
+  // stage's shared dX buffer (bf16 [rows][M]) in execution order: behind out_proj's dgrad, then for k = K-1 .. 0 behind the
+  // dgrad of block k's second and first Dense
+  int64_t debug_stem_snapshot_bytes() const { return (int64_t)d_.num_layers * 34 * rows() * d_.embed_channels; }
+  int64_t debug_snapshot_bytes() const { return debug_stem_snapshot_bytes() + (int64_t)(2 * nblocks() + 1) * rows() * d_.mlp_dims * 2; }
   int set_debug_snapshots(void* buf, int64_t bytes);
   // Debugging aid (tests/test_gpu_engine.py layer-by-layer check): device pointer, shape and element type (0 fp32, 1 bf16) of
   // an activation the TRAINING forward pass saved in the bound workspace -- "x_bf16", "h"[l], "h_mid"[l], "a1"[l], "qkv"[l],

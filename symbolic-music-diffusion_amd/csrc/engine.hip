@@ -760,6 +760,13 @@ int SmdEngine::backward_head(hipStream_t st) {
   const bool use_bf16_chain = resgrad_bf16 && M == 2048;
   // out_proj (models/ncsn.py:178): X = ao, dY = dpred
   RC(dense_bwd(out_proj_, W.ao, M, W.dpred, Cp_, R, W.dA_M, M, nullptr, 0, SMD_AUX_NONE, st, true));
+  // debug snapshots: copy i of the shared dX buffer, stream-ordered behind the dgrad that wrote it
+  auto hsnap = [&](int i) {
+    if (!dbg_snap_) return;
+    const size_t RM2 = (size_t)R * M * 2;
+    (void)hipMemcpyAsync(dbg_snap_ + debug_stem_snapshot_bytes() + (size_t)i * RM2, W.dA_M, RM2, hipMemcpyDeviceToDevice, st);
+  };
+  hsnap(0);
   {
     LnBwdArgs b;
     const bool tbk = trunk_bf16_on();
@@ -783,6 +790,7 @@ int SmdEngine::backward_head(hipStream_t st) {
     const FilmResP& p = blk_[k];
     // fc2 of the res block: y[k+1] = ya2 W + b + y[k]
     RC(res_bwd(p.r2, 2 * k + 1, W.ya2[k], W.dyb[k + 1]));
+    hsnap(1 + 2 * (K - 1 - k));
     {
       LnBwdArgs b;
       b.f = ln_args(nullptr, W.o1[k], R, p.ln2, params_);
@@ -794,6 +802,7 @@ int SmdEngine::backward_head(hipStream_t st) {
       RC(ln_bwd(b, st));
     }
     RC(res_bwd(p.r1, 2 * k, W.ya1[k], W.do1[k]));
+    hsnap(2 + 2 * (K - 1 - k));
     {
       LnBwdArgs b;
       b.f = trunk_bf16_on() ? ln_args(nullptr, reinterpret_cast<bf16_t*>(W.y[k]), R, p.ln1, params_)
@@ -877,6 +886,8 @@ int SmdEngine::debug_tensor(const char* name, int index, const void** ptr, int64
   if (n == "dpred") return set(W.dpred, R, Cp_, 1);
   if (n == "dyb" && layer(K + 1)) return set(W.dyb[index], R, M, 1);
   if (n == "do1" && layer(K)) return set(W.do1[index], R, M, 1);
+  if (n == "dss" && layer(K)) return set(W.dss[index], B, 2 * M, 0);
+  if (n == "zf1" && layer(K)) return set(W.zf1[index], B, 4 * F, 1);
   if (n == "dss_bf16" && layer(K)) return set(W.dss_bf16[index], B, 2 * M, 1);
   if (n == "dp" && layer(K)) return set(W.dp[index], B, 4 * F, 1);
   if (n == "df1" && layer(K)) return set(W.df1[index], B, 4 * F, 1);

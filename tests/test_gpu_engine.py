@@ -487,6 +487,132 @@ def test_encoder_backward_chain_from_snapshots(C, L, H, B):
           + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
 
 
+@pytest.mark.parametrize("arch,C,L,K,B", [("TransformerDDPM", 512, 6, 2, 256), ("DenseDDPM", 512, 3, 3, 512), ("TransformerDDPM", 146, 2, 3, 8)])
+def test_output_stage_backward_chain_from_snapshots(arch, C, L, K, B):
+    """The output stage's backward, teacher-forced like the encoder's: the shared dX buffer is copied out behind every dgrad
+    (smd_engine_debug_snapshots), so each kernel is checked in float64 on exactly its inputs -- the dgrads of out_proj and of
+    both Dense of every block (bf16), LayerNorm_o backward, the two FiLM + swish LayerNorm backwards of every block with their
+    residual-gradient add (bf16 dX), the per-sample dscale | dshift sums they accumulate (fp32), the LayerNorm parameter
+    gradients, the FiLM generator's two dgrads (bf16, the second through swish'), and `up`'s dgrad chained into LayerNorm_f's
+    backward (its dX lives in the buffer the encoder then overwrites, so the pair is checked as one).  With the encoder chain
+    and the weight-gradient tests, every kernel of loss_backward is pinned in situ."""
+    import bf16_emulation as E
+    import smd_amd.lib as lib
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    dense = arch == "DenseDDPM"
+    cfg = NetConfig(architecture=arch, data_channels=C, seq_len=32, num_layers=L, num_heads=8 if C == 512 else 16,
+                    num_mlp_layers=K, num_timesteps=1000)
+    model = N.Model(cfg, "cuda:0", seed=6)
+    g = torch.Generator().manual_seed(8)
+    for k_, v_ in model.engine.named_views().items():           # non-trivial LayerNorm affine
+        if k_.endswith(".scale"):
+            v_.copy_((1 + 0.1 * torch.randn(v_.shape, generator=g)).cuda())
+    model.engine.refresh_weights()
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    Lc = lib.get_lib()
+    nbytes = int(Lc.smd_engine_debug_snapshot_bytes(eng.h))
+    snap = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    lib.check(Lc.smd_engine_debug_snapshots(eng.h, snap.data_ptr(), nbytes))
+    x0, _ = data(B, (C,) if dense else (32, C))
+    try:
+        eng.loss_backward(x0.cuda(), None, None, seed=29, stage=0)
+        torch.cuda.synchronize()
+    finally:
+        lib.check(Lc.smd_engine_debug_snapshots(eng.h, None, 0))
+    S = 1 if dense else 32
+    R, M, Eh = B * S, 2048, 128
+    KB = L if dense else K                                        # blocks of the output stage
+    stem_bytes = L * 34 * R * Eh
+    assert nbytes == stem_bytes + (2 * KB + 1) * R * M * 2
+
+    def dA(i):
+        return snap[stem_bytes + i * R * M * 2: stem_bytes + (i + 1) * R * M * 2].view(torch.bfloat16).view(R, M).double()
+
+    T = lambda name, i=0: eng.debug_tensor(name, i).double()
+    pv = {k: v.double() for k, v in eng.named_views(eng.params).items()}
+    gv = eng.named_views(eng.grads)
+    rb = E.rb
+    worst = {}
+
+    def check(name, got, want, tol):
+        e = rel(got, want)
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert e < tol, f"{name}: rel {e:.2e}"
+
+    def dswish(z):
+        sg = torch.sigmoid(z)
+        return sg * (1 + z * (1 - sg))
+
+    def film_ln_bwd(x, dout, gamma, beta, ss):
+        """backward of swish(scale * LN(x) + shift): dx, dgamma, dbeta, dscale | dshift per sample"""
+        mean = x.mean(-1, keepdim=True)
+        rstd = torch.rsqrt((x * x).mean(-1, keepdim=True) - mean * mean + 1e-6)
+        xh = (x - mean) * rstd
+        n = xh * gamma + beta
+        sc = ss[:, :M].repeat_interleave(S, 0)
+        sh = ss[:, M:].repeat_interleave(S, 0)
+        dpre = dout * dswish(sc * n + sh)
+        dsc = (dpre * n).view(B, S, M).sum(1)
+        dsh = dpre.view(B, S, M).sum(1)
+        dn = dpre * sc
+        dxh = dn * gamma
+        dx = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+        return dx, (dn * xh).sum(0), dn.sum(0), torch.cat([dsc, dsh], 1)
+
+    # out_proj's dgrad and LayerNorm_o's backward
+    Cp = T("dpred").shape[1]
+    Wout = torch.zeros(M, Cp, dtype=torch.float64, device="cuda")
+    Wout[:, :C] = rb(pv["out_proj.kernel"])
+    check("d ao = d eps_hat Wout^T (bf16)", dA(0), rb(T("dpred") @ Wout.t()), 2e-4)
+    x = T("y", KB)
+    mean = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt((x * x).mean(-1, keepdim=True) - mean * mean + 1e-6)
+    xh = (x - mean) * rstd
+    dxh = dA(0) * pv["ln_o.scale"]
+    dx = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+    check("ln_o backward (bf16)", T("dyb", KB), rb(dx), 2e-4)
+    check("ln_o dgamma", gv["ln_o.scale"], (dA(0) * xh).sum(0).cpu(), 1e-5)
+    check("ln_o dbeta", gv["ln_o.bias"], dA(0).sum(0).cpu(), 1e-5)
+    for k in range(KB - 1, -1, -1):
+        pre, j = f"res.{k}", KB - 1 - k
+        d2 = dA(1 + 2 * j)
+        check("d ya2 = dy W2^T (bf16)", d2, rb(T("dyb", k + 1) @ rb(pv[pre + ".fc2.kernel"]).t()), 2e-4)
+        dx, dg, db, dss2 = film_ln_bwd(T("o1", k), d2, pv[pre + ".ln2.scale"], pv[pre + ".ln2.bias"], T("ss", k))
+        check("FiLM ln2 backward (bf16)", T("do1", k), rb(dx), 2e-4)
+        check("ln2 dgamma", gv[pre + ".ln2.scale"], dg.cpu(), 1e-5)
+        check("ln2 dbeta", gv[pre + ".ln2.bias"], db.cpu(), 1e-5)
+        d1 = dA(2 + 2 * j)
+        check("d ya1 = do1 W1^T (bf16)", d1, rb(T("do1", k) @ rb(pv[pre + ".fc1.kernel"]).t()), 2e-4)
+        dx, dg, db, dss1 = film_ln_bwd(T("y", k), d1, pv[pre + ".ln1.scale"], pv[pre + ".ln1.bias"], T("ss", k))
+        check("FiLM ln1 backward + residual (bf16)", T("dyb", k), rb(dx + T("dyb", k + 1)), 2e-4)
+        check("ln1 dgamma", gv[pre + ".ln1.scale"], dg.cpu(), 1e-5)
+        check("ln1 dbeta", gv[pre + ".ln1.bias"], db.cpu(), 1e-5)
+        check("dscale | dshift (fp32, both LayerNorms)", T("dss", k), dss2 + dss1, 1e-5)
+        assert torch.equal(eng.debug_tensor("dss", k).to(torch.bfloat16), eng.debug_tensor("dss_bf16", k))
+        fp = f"film.{k}"
+        check("dp = dss Wss^T (bf16)", T("dp", k), rb(T("dss_bf16", k) @ rb(pv[fp + ".ss.kernel"]).t()), 2e-4)
+        check("df1 = (dp W2^T) swish'(zf1) (bf16)", T("df1", k), rb((T("dp", k) @ rb(pv[fp + ".fc2.kernel"]).t()) * dswish(T("zf1", k))), 2e-4)
+    if not dense:
+        # `up`'s dgrad and LayerNorm_f's backward as one (the dX between them is overwritten by the encoder)
+        da = rb(T("dyb", 0) @ rb(pv["up.kernel"]).t())
+        x = T("h_last")
+        mean = x.mean(-1, keepdim=True)
+        rstd = torch.rsqrt((x * x).mean(-1, keepdim=True) - mean * mean + 1e-6)
+        xh = (x - mean) * rstd
+        dxh = da * pv["ln_f.scale"]
+        dx = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+        dh_in = snap[26 * R * Eh: 30 * R * Eh].view(torch.float32).view(R, Eh).double()       # slot 0 = layer L-1, segment dh_in
+        check("up dgrad + ln_f backward (fp32)", dh_in, dx, 1e-4)
+        check("up dgrad + ln_f backward (bf16 copy)", T("dhb", 2 * L), rb(dx), 3e-4)
+        check("ln_f dgamma", gv["ln_f.scale"], (da * xh).sum(0).cpu(), 1e-4)
+        check("ln_f dbeta", gv["ln_f.bias"], da.sum(0).cpu(), 1e-4)
+    print(f"{arch} C={C} L={L} K={K} B={B}: output-stage backward chain vs float64 of each kernel's own inputs:\n     "
+          + "\n     ".join(f"{k_} {v_:.1e}" for k_, v_ in worst.items()))
+
+
 def test_optimizer_step_matches_oracle():
     ocfg, p, model = make(C=42, L=2, K=1)
     B = 4
