@@ -729,6 +729,12 @@ struct MlpHsBwdArgs {
 // REGF: the wave's a2 / dh B fragments (its two samples x its token half: 16 x 16 bytes per lane) are read from LDS ONCE and
 // kept in registers for all 16 chunks (the kernel needs 88 registers of the 256 two waves per SIMD may take) instead of being
 // re-read every chunk: 16 of a chunk's ~32 ds_read_b128 and their latency in front of the first MFMA chain are gone.
+// Piece swizzle of the 64-byte-row tiles (S3, u, dz): 16-byte piece p of row r lives at position p ^ hb_swz((r >> 2) & 3).  The
+// permutation 0 2 3 1 instead of the identity because ds_read_b128 serves lanes {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} / ...
+// together, not {0-15} / {16-31}: with the identity the rows j and j +- 4 of neighbouring k-groups met on one slot (2-way
+// conflict on every S3 and dz fragment read: 24 of a chunk's 40 conflict cycles, tools/lds_conflicts.py).
+__device__ __forceinline__ int hb_swz(int x) { return (0x78 >> (2 * x)) & 3; }
+
 template <bool REGF>
 __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[HB_SMEM];
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
     const int rl = w * 4 + (lane >> 4);                                   // row of a 32-row round of 256-B rows
     const uint32_t v256 = (uint32_t)rl * 256u + (uint32_t)(((lane & 15) ^ (rl & 15)) * 16);
     const int k3 = w * 16 + (lane >> 2);                                  // S3: 16 rows of 64 B per wave, 4 lanes per row
-    const uint32_t v3 = (uint32_t)k3 * (uint32_t)(a.M * 2) + (uint32_t)((((lane & 3) ^ ((k3 >> 2) & 3))) * 16);
+    const uint32_t v3 = (uint32_t)k3 * (uint32_t)(a.M * 2) + (uint32_t)((((lane & 3) ^ hb_swz((k3 >> 2) & 3))) * 16);
     const __amdgpu_buffer_rsrc_t w1t_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1t), 0, a.M * E_DIM * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2), 0, a.M * E_DIM * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1), 0, a.M * E_DIM * 2, 0x00020000);
@@ -782,7 +788,7 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
         for (int e = 0; e < 4; ++e) acc[sl][mt][e] = 0.0f;
 
     const int arow = (ht * 16 + j) * 256;                               // A row of S1 / S2
-    const int tswz = (tok >> 2) & 3;
+    const int tswz = hb_swz((tok >> 2) & 3);
     const int srow = tid >> 2, spc = tid & 3;                           // store mapping: (token row of the group, 16-B piece)
     bf16x8_t a2f[REGF ? SPW : 1][4], dhf[REGF ? SPW : 1][4];
     if constexpr (REGF) {
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int kr = (ht * 4 + mt) * 16 + j;
-          kf[mt] = *reinterpret_cast<lds_b128_ptr>(s3 + kr * 64 + ((g ^ ((kr >> 2) & 3)) << 4));
+          kf[mt] = *reinterpret_cast<lds_b128_ptr>(s3 + kr * 64 + ((g ^ hb_swz((kr >> 2) & 3)) << 4));
         }
 #pragma unroll
         for (int sl = 0; sl < SPW; ++sl) {
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
           for (int mt = 0; mt < 4; ++mt) acc[sl][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[mt], fz, acc[sl][mt], 0, 0, 0);
         }
         // u / dz of this chunk -> global, one 16-B piece of a 64-B row segment per thread and tensor
-        const int po = srow * 64 + ((spc ^ ((srow >> 2) & 3)) << 4);
+        const int po = srow * 64 + ((spc ^ hb_swz((srow >> 2) & 3)) << 4);
         const bf16x8_t vu = *reinterpret_cast<lds_b128_ptr>(L + HB_U + po);
         const bf16x8_t vz = *reinterpret_cast<lds_b128_ptr>(L + HB_DZ + po);
         const size_t go = (row0 + srow) * (size_t)a.M + hbase + c * HB_CH + spc * 8;
@@ -991,7 +997,10 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
       for (int i = 0; i < 8; ++i) {
         x[i].x = (pp[0][i].x + pp[1][i].x) + (pp[2][i].x + pp[3][i].x);
         x[i].y = (pp[0][i].y + pp[1][i].y) + (pp[2][i].y + pp[3][i].y);
-        *reinterpret_cast<float2*>(smem + AT_XS + ((w * 8 + i) * E_DIM + lane * 2) * 4) = x[i];
+        // 16-byte slot s of row r lives at s ^ (r & 15): the epilogue reads one slot per ROW and lane (512-byte rows: all 16
+        // lanes of a ds_read_b128 group would meet on one slot, a 16-way conflict = 240 of the kernel's ~290 conflict cycles per
+        // wave, tools/lds_conflicts.py)
+        *reinterpret_cast<float2*>(smem + AT_XS + (w * 8 + i) * (E_DIM * 4) + (((lane >> 1) ^ ((w * 8 + i) & 15)) << 4) + (lane & 1) * 8) = x[i];
         if (a.h_comb) *reinterpret_cast<float2*>(a.h_comb + (row0 + w * 8 + i) * E_DIM + lane * 2) = x[i];
       }
     }
@@ -1169,7 +1178,7 @@ __global__ __launch_bounds__(256) void attn_block_fwd_kernel(AttnArgs a) {
   float4 res[4], bo[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    if (a.h_parts) res[g] = *reinterpret_cast<const float4*>(smem + AT_XS + (l31 * E_DIM + w * 32 + 4 * kh + 8 * g) * 4);
+    if (a.h_parts) res[g] = *reinterpret_cast<const float4*>(smem + AT_XS + l31 * (E_DIM * 4) + (((w * 8 + kh + 2 * g) ^ sw) << 4));
     else res[g] = *reinterpret_cast<const float4*>(a.h_in + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g);
     bo[g] = *reinterpret_cast<const float4*>(a.b_o + w * 32 + 4 * kh + 8 * g);
   }
@@ -1291,19 +1300,26 @@ __device__ __forceinline__ bf16x4_t tr_read(unsigned addr) {
   return v;
 }
 
+// Slot swizzle of this kernel's 256-byte-row tiles: 16-byte slot s of row r lives at s ^ ab_swz(r & 15), the two bit pairs of the
+// row index SWAPPED.  With the plain s ^ (r & 15) the transposing reads (32 lanes = 4 consecutive rows x 64 bytes) found all four
+// rows on the same four slots -- the rows differ in r & 3, which only permuted the low slot bits: a 4-way conflict on each of the
+// 24 ds_read_b64_tr_b16 per wave (144 of ~210 conflict cycles, tools/lds_conflicts.py); swapped, r & 3 selects the 64-byte
+// quarter.  The ds_read_b128 fragment reads (16 distinct r & 15 per lane group) are conflict-free under any bijection.
+__device__ __forceinline__ int ab_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
 template <int DH>
 __global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[AB_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t row0 = (size_t)blockIdx.x * S_TOK;
-  const int kh = lane >> 5, l31 = lane & 31, sw = l31 & 15;
+  const int kh = lane >> 5, l31 = lane & 31, sw = ab_swz(l31 & 15);
   lds_byte_ptr L = (lds_byte_ptr)smem;
   const unsigned L0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
-  // ---- DMA: 256-B-row tiles, 16 rows per round over the 4 waves, source chunk = position ^ (row & 15)
+  // ---- DMA: 256-B-row tiles, 16 rows per round over the 4 waves, source chunk = position ^ ab_swz(row & 15)
   const int rl = w * 4 + (lane >> 4);
-  const uint32_t csw = (uint32_t)(((lane & 15) ^ rl) * 16);
+  const uint32_t csw = (uint32_t)(((lane & 15) ^ ab_swz(rl)) * 16);
   unsigned char* lds_w = smem + w * 1024;
   const __amdgpu_buffer_rsrc_t wo_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wo), 0, 128 * 256, 0x00020000);
   const __amdgpu_buffer_rsrc_t wq_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.Wqkv), 0, 128 * 768, 0x00020000);
@@ -1411,8 +1427,8 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         const int r0 = 16 * ks2 + 4 * kh + (ig >> 2), r1 = r0 + 8;
         Frag8 fa;
-        fa.h[0] = tr_read(L0 + AB_QKV + 8192 + r0 * 256 + (((fcol >> 3) ^ (r0 & 15)) << 4) + (fcol & 7) * 2);
-        fa.h[1] = tr_read(L0 + AB_QKV + 8192 + r1 * 256 + (((fcol >> 3) ^ (r1 & 15)) << 4) + (fcol & 7) * 2);
+        fa.h[0] = tr_read(L0 + AB_QKV + 8192 + r0 * 256 + (((fcol >> 3) ^ ab_swz(r0 & 15)) << 4) + (fcol & 7) * 2);
+        fa.h[1] = tr_read(L0 + AB_QKV + 8192 + r1 * 256 + (((fcol >> 3) ^ ab_swz(r1 & 15)) << 4) + (fcol & 7) * 2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, dst_[ks2].v, dq, 0, 0, 0);
@@ -1464,8 +1480,8 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ++ks2) {
         const int r0 = 16 * ks2 + 4 * kh + (ig >> 2), r1 = r0 + 8;
-        const int o0 = r0 * 256 + (((fcol >> 3) ^ (r0 & 15)) << 4) + (fcol & 7) * 2;
-        const int o1 = r1 * 256 + (((fcol >> 3) ^ (r1 & 15)) << 4) + (fcol & 7) * 2;
+        const int o0 = r0 * 256 + (((fcol >> 3) ^ ab_swz(r0 & 15)) << 4) + (fcol & 7) * 2;
+        const int o1 = r1 * 256 + (((fcol >> 3) ^ ab_swz(r1 & 15)) << 4) + (fcol & 7) * 2;
         Frag8 fqT, fdT;
         fqT.h[0] = tr_read(L0 + AB_QKV + o0);
         fqT.h[1] = tr_read(L0 + AB_QKV + o1);
