@@ -252,6 +252,8 @@ int smd_set_timestep(int32_t* t_ptr, int32_t t, void* stream);
  * "tn_split_model": 1 = split-K of the 128-wide weight gradients chosen for whole rounds of 256 workgroups;
  * "tn128_loader_waves": 1 = the 128-wide weight-gradient kernel runs four extra waves that only issue LDS-DMA (0 needs the
  *               experiment build);
+ * "gemm_nt_form": 0 (default) = the 128-column kernel picks its tile form from the shape; 1 .. 6 force <64,2>, <128,2>,
+ *               <128,2,two K-groups>, <64,2,two K-groups>, <128,3>, <64,3,two K-groups> (tools/gemm_nt_forms_ab.py);
  * further keys ("ln_bwd_wide", "ln_fwd_wide", "ln_bwd_narrow", "gemm_nt_deep", "gemm_nt_kg", "mlp_variant", ...) select
  * between equivalent kernels for A/B runs; unknown keys return < 0. */
 int smd_set_tuning(const char* key, int value);

@@ -236,7 +236,7 @@ void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N
 // process-wide kernel-selection knobs (smd_set_tuning in the C-ABI)
 namespace {
 struct Knob { const char* key; int value; };
-Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_nt256_pk", 1}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 3}, {"gemm_nt_kg", 1}, {"mlp_hs_dbg", 0}, {"ln_excl", 0}, {"tn_exclusive_cu", 2}, {"tn_split_model", 1}, {"tn128_loader_waves", 1}, {"tn_mode", 0}};
+Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_nt256_pk", 1}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 3}, {"gemm_nt_kg", 1}, {"mlp_hs_dbg", 0}, {"ln_excl", 0}, {"tn_exclusive_cu", 2}, {"tn_split_model", 1}, {"tn128_loader_waves", 1}, {"tn_mode", 0}, {"gemm_nt_form", 0}};
 }
 int smd_tuning_set(const char* key, int value) {
   for (Knob& k : g_knobs)
@@ -266,7 +266,15 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
   const long wg128 = (long)((M + 127) / 128) * tiles_n;
   const long wg64 = (long)((M + 63) / 64) * tiles_n;
   const bool deep = K >= 8 * BK && smd_tuning_get("gemm_nt_deep");
-  if (M <= 32 || !(wg128 >= 512 || wg64 >= 256 || M <= 64)) {
+  // measurement knob (tools/gemm_nt_forms_ab.py): force one tile form for the shapes that have a choice
+  const int form = M > 64 ? smd_tuning_get("gemm_nt_form") : 0;
+  if (form == 1) launch_bm<64, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (form == 2) launch_bm<128, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (form == 3 && K % (2 * BK) == 0) launch_bm<128, 2, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (form == 4 && K % (2 * BK) == 0) launch_bm<64, 2, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (form == 5) launch_bm<128, 3>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (form == 6 && K % (2 * BK) == 0) launch_bm<64, 3, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  else if (M <= 32 || !(wg128 >= 512 || wg64 >= 256 || M <= 64)) {
     // K >= 1024: two K-groups of four waves per workgroup (A/B: 8-18 % over one group with a 4-deep ring; deeper rings
     // -- 7 stages, or 2 groups x 4 stages -- gain nothing: the step time follows the LDS-DMA landing cadence)
     if (deep && K >= 16 * BK && K % (2 * BK) == 0 && smd_tuning_get("gemm_nt_kg")) launch_bm<32, 3, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
@@ -274,6 +282,11 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
     else launch_bm<32, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   } else if (wg128 >= 512) {
     launch_bm<128, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  } else if (wg64 <= 256 && K >= 16 * BK && K % (2 * BK) == 0 && smd_tuning_get("gemm_nt_kg")) {
+    // exactly one 64-row workgroup per CU and a long K (out_proj of one sampler chain, 4096 x 2048 -> 512; out_proj of the
+    // C = 146 network): two K-groups of four waves = two waves per SIMD on the same tile, 19.6 -> 16.5 us and 18.9 -> 15.8 us
+    // (profiles/r4w_gemm_nt_forms.txt); with two workgroups per CU (8192 x 2048 -> 512) the one-group form is the faster one
+    launch_bm<64, 2, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   } else {
     launch_bm<64, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);   // 4 stages = 96 KiB: 1 workgroup per CU instead of 3, slower (A/B)
   }
