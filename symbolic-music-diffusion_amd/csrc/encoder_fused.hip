@@ -492,14 +492,23 @@ struct MlpHsArgs {
     ts[i] = (uint32_t)__builtin_amdgcn_s_memtime();                          \
     __builtin_amdgcn_sched_barrier(0);                                       \
   }
-template <int NS, bool TS = false>
-__global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
+// NWV = 16 (the default for groups of four samples; mlp_variant = 5 selects the eight-wave form): sixteen waves, four per SIMD;
+// the second group of eight takes the second half of the workgroup's samples (NSW = NS / 2 per wave: 128 registers instead of
+// 200), every DMA round covers 64 tile rows instead of 32.  Bit-identical; 18.9 -> 18.2 us isolated, sample step +1-2 %
+// (profiles/r4w_mlp_fwd16_ab.txt) -- the phases stay barrier-synchronous, so the gain is only the latency four waves hide.
+template <int NS, bool TS = false, int NWV = 8>
+__global__ __launch_bounds__(64 * NWV) void mlp_hs_fwd_kernel(MlpHsArgs a) {
+  constexpr int SGS = NWV / 8;                   // sample groups of waves
+  constexpr int NSW = NS / SGS;                  // samples per wave
+  constexpr int RR = 32 * SGS;                   // tile rows per DMA round
+  constexpr int WR = 4 / SGS;                    // DMA rounds per 128-row weight slice
+  static_assert(NS % SGS == 0 && (NWV == 8 || NWV == 16), "mlp_hs_fwd: wave count");
   uint32_t ts[36];
   HS_TS(0)
   __shared__ __attribute__((aligned(16))) unsigned char smem[HS_TILE + NS * 8192];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hg = w & 3, th = w >> 2;
+  const int hg = w & 3, th = (w >> 2) & 1, s_lo = (w >> 3) * NSW;       // this wave's samples: s_lo .. s_lo + NSW - 1
   const int q = blockIdx.x & (HS_NQ - 1), grp = blockIdx.x >> 2;
   const size_t row0 = (size_t)grp * (S_TOK * NS);
   const int g = lane >> 4, j = lane & 15;
@@ -516,15 +525,15 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
   const __amdgpu_buffer_rsrc_t w1_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W1t), 0, a.M * E_DIM * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t w2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.W2t), 0, a.M * E_DIM * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t a2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.a2 + row0 * E_DIM), 0, NS * 8192, 0x00020000);
-  const uint32_t w2_round = (uint32_t)(32 * a.M * 2);
+  const uint32_t w2_round = (uint32_t)(RR * a.M * 2);
   unsigned char* lds_w = smem + w * 1024;
   auto stage_chunk = [&](int c, int buf) {
     unsigned char* d1 = lds_w + buf * HS_WBUF;
     const uint32_t h0 = (uint32_t)(hbase + c * CH);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) glds16(w1_rsrc, w1_v, h0 * 256u + (uint32_t)(r * 8192), d1 + r * 8192);
+    for (int r = 0; r < WR; ++r) glds16(w1_rsrc, w1_v, h0 * 256u + (uint32_t)(r * RR * 256), d1 + r * RR * 256);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) glds16(w2_rsrc, w2_v, h0 * 2u + (uint32_t)r * w2_round, d1 + W_SLICE + r * 8192);
+    for (int r = 0; r < WR; ++r) glds16(w2_rsrc, w2_v, h0 * 2u + (uint32_t)r * w2_round, d1 + W_SLICE + r * RR * 256);
   };
   float4 bnext[2];
   auto fetch_bias = [&](int c) {
@@ -533,22 +542,23 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
   };
   fetch_bias(0);
 #pragma unroll
-  for (int s = 0; s < NS; ++s) glds16(a2_rsrc, w1_v, (uint32_t)(s * 8192), lds_w + HS_TILE + s * 8192);      // a2 tiles
+  for (int s = 0; s < NS / SGS; ++s) glds16(a2_rsrc, w1_v, (uint32_t)(s * RR * 256), lds_w + HS_TILE + s * RR * 256);      // a2 tiles
   stage_chunk(0, 0);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the a2 tiles (and the bias) have landed; chunk 0 may fly on
+  if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the a2 tiles (and the bias) have landed; chunk 0 may fly on
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   // B fragments of a2^T per sample (lane = token th*16 + j, k-chunk 4 ks + g), kept in registers for the whole kernel
-  bf16x8_t a2f[NS][4];
+  bf16x8_t a2f[NSW][4];
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NSW; ++s)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-      a2f[s][ks] = *reinterpret_cast<lds_b128_ptr>(L + HS_TILE + (s * 32 + tok) * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
+      a2f[s][ks] = *reinterpret_cast<lds_b128_ptr>(L + HS_TILE + ((s_lo + s) * 32 + tok) * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
 
-  f32x4_t acc[NS][2];
+  f32x4_t acc[NSW][2];
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NSW; ++s)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -564,7 +574,8 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
     // The W1 slice of chunk c has landed (vmcnt(4): its W2 slice, issued right behind it, may still be in flight: it
     // is only needed after the second barrier); every wave is done with iteration c-1, so the other weight buffer and
     // the u tiles are free (the first pass also orders the a2 fragment reads before the u writes).
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     HS_TS(3 + c * 8)
@@ -585,9 +596,9 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
         for (int ks = 0; ks < 4; ++ks) wf[mt][ks] = *reinterpret_cast<lds_b128_ptr>(s1 + arow + mt * 16 * 256 + (((ks * 4 + g) ^ j) << 4));
       if constexpr (TS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       HS_TS(4 + c * 8)
-      f32x4_t z[NS][2];
+      f32x4_t z[NSW][2];
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int s = 0; s < NSW; ++s)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -595,19 +606,19 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NSW; ++s)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) z[s][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][ks], a2f[s][ks], z[s][mt], 0, 0, 0);
       if constexpr (TS) {                  // the last MFMA of every accumulator has retired
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NSW; ++s)
 #pragma unroll
           for (int mt = 0; mt < 2; ++mt) asm volatile("v_mov_b32 %0, %0" : "+v"(z[s][mt][0]));
       }
       HS_TS(5 + c * 8)
       // + b1, GELU -> u[sample][token][hidden] (hidden of z[s][mt][e]: hg*32 + mt*16 + 4g + e)
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int s = 0; s < NSW; ++s)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const float bb[4] = {bcur[mt].x, bcur[mt].y, bcur[mt].z, bcur[mt].w};
@@ -615,14 +626,16 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) uu[e] = f2bf(geluf_(z[s][mt][e] + bb[e]));
           const int hid = hg * 32 + mt * 16 + 4 * g;
-          *reinterpret_cast<bf16x4_t*>(smem + HS_TILE + (s * 32 + tok) * 256 + (((hid >> 3) ^ (tok & 15)) << 4) + (hid & 7) * 2) = uu;
+          *reinterpret_cast<bf16x4_t*>(smem + HS_TILE + ((s_lo + s) * 32 + tok) * 256 + (((hid >> 3) ^ (tok & 15)) << 4) + (hid & 7) * 2) = uu;
         }
     }
     if constexpr (TS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     HS_TS(6 + c * 8)
     // u tiles written; the W2 slice of this chunk has landed: behind it only the next chunk's 2 bias loads + 8 DMAs
-    if (more) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (more) {
+      if constexpr (NWV == 8) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     HS_TS(7 + c * 8)
@@ -634,11 +647,11 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) vf[mt][ks] = *reinterpret_cast<lds_b128_ptr>(s2 + arow + mt * 16 * 256 + (((ks * 4 + g) ^ j) << 4));
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
+      for (int s = 0; s < NSW; ++s) {
         bf16x8_t uf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-          uf[ks] = *reinterpret_cast<lds_b128_ptr>(L + HS_TILE + (s * 32 + tok) * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
+          uf[ks] = *reinterpret_cast<lds_b128_ptr>(L + HS_TILE + ((s_lo + s) * 32 + tok) * 256 + (((ks * 4 + g) ^ (tok & 15)) << 4));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -647,7 +660,7 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
     }
     if constexpr (TS) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int s = 0; s < NSW; ++s)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) asm volatile("v_mov_b32 %0, %0" : "+v"(acc[s][mt][0]));
     }
@@ -661,17 +674,17 @@ __global__ __launch_bounds__(512) void mlp_hs_fwd_kernel(MlpHsArgs a) {
   {
     float* dst = a.part + ((size_t)q * a.rows + row0) * E_DIM;
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int s = 0; s < NSW; ++s)
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const int n0 = hg * 32 + mt * 16 + 4 * g;
         float4 v = make_float4(acc[s][mt][0], acc[s][mt][1], acc[s][mt][2], acc[s][mt][3]);
         if (q == 0) {
-          const float4 r = *reinterpret_cast<const float4*>(a.h_res + (row0 + s * 32 + tok) * E_DIM + n0);
+          const float4 r = *reinterpret_cast<const float4*>(a.h_res + (row0 + (s_lo + s) * 32 + tok) * E_DIM + n0);
           const float4 bb = *reinterpret_cast<const float4*>(a.b2 + n0);
           v.x += bb.x + r.x; v.y += bb.y + r.y; v.z += bb.z + r.z; v.w += bb.w + r.w;
         }
-        *reinterpret_cast<float4*>(dst + (size_t)(s * 32 + tok) * E_DIM + n0) = v;
+        *reinterpret_cast<float4*>(dst + (size_t)((s_lo + s) * 32 + tok) * E_DIM + n0) = v;
       }
     if constexpr (TS) {                    // 36 stamps per wave at the head of the workgroup's partial tile (40 dwords apart)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1584,7 +1597,8 @@ int launch_mlp_block_fwd_hs(const bf16_t* a2, const float* h_res, int rows, cons
   if (a.dbg & 64) {                // phase stamps instead of the result (tools/mlp_hs_phases.py)
     SMD_ARG_CHECK(ns == 4 && M == 2048, "mlp_block_fwd_hs: the instrumented instantiation is built for groups of 4 samples, hidden 2048");
     hipLaunchKernelGGL((mlp_hs_fwd_kernel<4, true>), grid, block, 0, st, a);
-  } else if (ns == 4) hipLaunchKernelGGL(mlp_hs_fwd_kernel<4>, grid, block, 0, st, a);
+  } else if (ns == 4 && smd_tuning_get("mlp_variant") != 5) hipLaunchKernelGGL((mlp_hs_fwd_kernel<4, false, 16>), grid, dim3(1024), 0, st, a);
+  else if (ns == 4) hipLaunchKernelGGL(mlp_hs_fwd_kernel<4>, grid, block, 0, st, a);     // mlp_variant = 5: the eight-wave form (A/B, tools/mlp_fwd16_ab.py)
   else if (ns == 2) hipLaunchKernelGGL(mlp_hs_fwd_kernel<2>, grid, block, 0, st, a);
   else hipLaunchKernelGGL(mlp_hs_fwd_kernel<1>, grid, block, 0, st, a);
   SMD_LAUNCH_CHECK();
