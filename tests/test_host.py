@@ -391,3 +391,33 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="4", RANK="0"), timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout) and r.stdout.strip() == ""
+
+
+def test_shipped_lds_layouts_are_conflict_free_under_the_real_lane_groups():
+    """tools/lds_conflicts.py: the LDS bank model of gfx950 with the lane groups ds_read_b128 / ds_write_b64 / the transposing
+    read really use (MI355X_MICROARCH.md).  The layouts the fused encoder kernels ship with must have no conflict on any read;
+    what remains is the inherent 2-way conflict of the 8-byte writes of four bf16 per lane.  The
+    round-3 layouts are kept in the model as the counter-example (they were designed for lane groups of 16 consecutive lanes)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_conflicts", os.path.join(root, "tools", "lds_conflicts.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+
+    def extra(accesses):
+        return {name: m.cycles(kind, fn)[1] for name, kind, _count, fn in accesses}
+
+    shipped = [m.mlp_hs_bwd(lambda x: (0x78 >> (2 * x)) & 3), m.mlp_hs_fwd(), m.attn_block_fwd(True),
+               m.attn_block_bwd(lambda r: ((r & 3) << 2) | ((r >> 2) & 3))]
+    for acc in shipped:
+        for name, e in extra(acc).items():
+            kind = next(k for n, k, _c, _f in acc if n == name)
+            if kind == "write_b64" and "72-B" not in name and "fp32" not in name:
+                assert e == 4, (name, e)                 # 2-way on each of the four 16-lane groups: inherent
+            else:
+                assert e == 0, (name, e)
+    # the layouts they replaced: every one of these reads conflicted
+    old = extra(m.mlp_hs_bwd(lambda x: x))
+    assert old["S3 A fragments (64-B rows)"] == 4 and old["dz B fragments (64-B rows)"] == 4
+    assert extra(m.attn_block_fwd(False))["residual rows, fp32 (epilogue reads)"] == 60
+    assert extra(m.attn_block_bwd(lambda r: r))["transposing reads of k, q, dO (first rows)"] == 2
