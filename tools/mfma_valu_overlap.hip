@@ -66,7 +66,12 @@ __global__ __launch_bounds__(512) void k(float* out, int mode, int phases, int n
       else { run_v(s, nv / 2); __syncthreads(); run_m(s, nm / 2); __syncthreads(); }
     } else if (mode == 5) { run_mv(s, nm / 2); }
     else if (mode == 6) { run_m(s, nm / 2); }
-    else { run_v(s, nv / 2); }
+    else if (mode == 7) { run_v(s, nv / 2); }
+    else {        // 8 / 9 / 10: whole CUs -- even workgroups M, odd workgroups V (8: only the even ones work, 9: only the odd ones)
+      const bool even = (blockIdx.x & 1) == 0;
+      if (even && mode != 9) run_m(s, nm / 2);
+      if (!even && mode != 8) run_v(s, nv / 2);
+    }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = s.c0[0] + s.c1[1] + s.c2[2] + s.c3[3] + s.x0 + s.x1 + s.x2 + s.x3 + s.y0 + s.y1 + s.y2 + s.y3;
 }
@@ -77,9 +82,10 @@ int main() {
   const char* names[] = {"M alone (one wave per SIMD)", "V alone (one wave per SIMD)", "M beside V (two waves per SIMD, one each)",
                          "both waves: M/2 ; barrier ; V/2 ; barrier (lockstep)", "first wave M/2 ; V/2, second wave V/2 ; M/2 (de-phased)",
                          "both waves: 1 MFMA + 8 VALU interleaved (M/2 + V/2 each)", "M only, split over both waves (M/2 each)",
-                         "V only, split over both waves (V/2 each)"};
-  float t[8];
-  for (int mode = 0; mode < 8; ++mode) {
+                         "V only, split over both waves (V/2 each)", "half of the CUs: M (the other half idle)",
+                         "half of the CUs: V (the other half idle)", "half of the CUs M, the other half V, at the same time"};
+  float t[11];
+  for (int mode = 0; mode < 11; ++mode) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     hipLaunchKernelGGL(k, dim3(256), dim3(512), 0, 0, out, mode, 5, nm, nv);
     CK(hipEventRecord(a));
