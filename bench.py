@@ -72,8 +72,13 @@ def parse(argv=None):
                     help="N > 1 GPUs: wire format of the gradient all-reduce (bf16 halves the xGMI bytes; off by default)")
     ap.add_argument("--dp-algorithm", choices=["all_reduce", "rs_ag"], default="all_reduce",
                     help="N > 1 GPUs: one all_reduce per bucket, or reduce_scatter + all_gather (one direct hop per phase on the xGMI mesh)")
-    ap.add_argument("--dp-layer-buckets", type=int, default=1,
-                    help="N > 1 GPUs: 1 = the stem slice is reduced per encoder layer behind the engine's per-layer gradient events")
+    ap.add_argument("--dp-layer-buckets", type=int, default=0,
+                    help="N > 1 GPUs: 1 = the stem slice is reduced per encoder layer behind the engine's per-layer gradient events "
+                         "(6 more collectives per step; off until measured to win on RCCL)")
+    ap.add_argument("--dp-dry-run", action="store_true",
+                    help="one GPU: two ranks share cuda:0 over gloo and walk the multi-GPU code path (CUDA tensors, communication "
+                         "stream, gradient events) with kernels of a collective's shape on the communication stream; checks that the "
+                         "reduced gradients are bitwise the same with and without that load and on both ranks")
     ap.add_argument("--sampler-chains", type=int, default=2, choices=[1, 2],
                     help="graph-replayed sampling as two concurrent half-batch chains (default) or one chain")
     ap.add_argument("--no-roofline-microbench", action="store_true",
@@ -92,6 +97,13 @@ def self_launch_if_needed(a) -> None:
         if int(env_world) != a.gpus:
             raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={env_world}")
         return
+    if a.dp_dry_run and a.gpus <= 1:
+        a.gpus = 2
+        os.environ["SMD_BENCH_SHARE_DEVICE"] = "1"
+        if "--gpus" not in " ".join(sys.argv[1:]):
+            sys.argv += ["--gpus", "2"]
+        else:
+            raise SystemExit("bench.py: --dp-dry-run launches its own two ranks on one GPU; drop --gpus")
     if a.gpus <= 1:
         return
     import torch
@@ -110,6 +122,42 @@ def self_launch_if_needed(a) -> None:
     log(f"launching {a.gpus} ranks: {' '.join(cmd)}")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def dp_dry_run(a, rank, world, dev, dist, comm):
+    """--dp-dry-run: the data-parallel train step on CUDA tensors with a communication stream that is really busy.  Three
+    trajectories of `steps` train steps from the same state and draws: (1) reduction with emulated load, (2) again (bitwise
+    repeatable?), (3) without the load.  All three must leave bitwise the same parameters, on both ranks."""
+    import torch
+    a.mode = "train"
+    results = {}
+    for tag, load in (("load_a", True), ("load_b", True), ("no_load", False)):
+        torch.manual_seed(0)
+        comm.emulate_load = load
+        w = Workload(a, a.config, a.dtype, rank, world, dev, comm)
+        for _ in range(a.steps):
+            w.one_train()
+        torch.cuda.synchronize()
+        results[tag] = (w.opt.engine.params.clone(), w.opt.engine.grads.clone(), float(w.final_loss()))
+        del w
+        torch.cuda.empty_cache()
+    same = {f"{x}=={y}": bool(torch.equal(results[x][0], results[y][0]) and torch.equal(results[x][1], results[y][1]))
+            for x, y in (("load_a", "load_b"), ("load_a", "no_load"))}
+    # both ranks hold the same reduced gradient and the same parameters
+    digest = torch.stack([results["load_a"][0].double().sum(), results["load_a"][1].double().sum()]).to(dev)
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    ranks_agree = all(bool(torch.equal(g, gathered[0])) for g in gathered)
+    ok = all(same.values()) and ranks_agree
+    if rank == 0:
+        print(json.dumps({"dp_dry_run": {"ok": ok, "bitwise": same, "ranks_agree": ranks_agree, "steps": a.steps, "world": world,
+                                         "final_loss": results["load_a"][2], "comm": comm.describe(),
+                                         "what": "two ranks on one GPU over gloo, CUDA gradient tensors, communication stream running a copy + add "
+                                                 "of every chunk beside the backward pass; not a measurement"}}))
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
 
 
 def cpu_baseline(cfg_name: str, batch: int):
@@ -503,13 +551,25 @@ def main():
     for kv in a.tuning:
         k, _, v = kv.partition("=")
         lib.check(lib.get_lib().smd_set_tuning(k.encode(), int(v)))
-    comm = (GradComm(buckets=a.dp_buckets, payload=a.dp_payload, algorithm=a.dp_algorithm, layer_buckets=bool(a.dp_layer_buckets))
+    comm = (GradComm(buckets=a.dp_buckets, payload=a.dp_payload, algorithm=a.dp_algorithm, layer_buckets=bool(a.dp_layer_buckets),
+                     measure_exposed=True, emulate_load=a.dp_dry_run)
             if world > 1 else None)
+    if a.dp_dry_run:
+        return dp_dry_run(a, rank, world, dev, dist, comm)
     do_train, do_sample = a.mode in ("both", "train"), a.mode in ("both", "sample")
 
     w = Workload(a, a.config, a.dtype, rank, world, dev, comm)
     log(f"rank {rank}: model + buffers ready, warming up")
+    if comm is not None:
+        comm.exposed_comm_us()                                     # drop what model set-up recorded
+    c0 = comm.collectives if comm is not None else 0
     blocks = run_blocks(w, a, dist, do_train, do_sample, a.steps, a.warmup, a.repeats)
+    dp_stats = {}
+    if comm is not None and do_train:
+        n_train = (max(a.warmup, 1) + a.steps * max(a.repeats, 1))
+        ex = comm.exposed_comm_us()
+        dp_stats = {"collectives_per_step": round((comm.collectives - c0) / n_train, 2),
+                    "exposed_comm_us": None if ex is None else round(ex, 1)}
     fwd = FLOP_FWD_PER_SEQ[a.config] * a.batch
     head = summarise(blocks, a.steps, world, do_train, do_sample, fwd)
     loss = w.final_loss() if do_train else float("nan")
@@ -573,8 +633,10 @@ def main():
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,
-                       **({"dp": {"algorithm": a.dp_algorithm, "buckets_per_stage": a.dp_buckets, "payload": a.dp_payload,
-                                  "layer_buckets": bool(a.dp_layer_buckets)}} if world > 1 else {}),
+                       **({"dp": {**comm.describe(), "collectives_per_step": dp_stats.get("collectives_per_step"),
+                                  "exposed_comm_us": dp_stats.get("exposed_comm_us"),
+                                  "what": "exposed_comm_us = mean stall of the compute stream at GradComm.wait() per train step (HIP events)"}}
+                          if world > 1 else {}),
                        "sample_step": "eager" if a.no_graph else ("hipGraph replay, 2 concurrent half-batch chains" if nch == 2 else "hipGraph replay"),
                        "rng": a.rng_impl},
             "repeats": a.repeats, "block_values": head["block_values"], "spread": head["spread"],

@@ -34,6 +34,9 @@ typedef struct smd_engine smd_engine;
 
 const char* smd_last_error(void);
 int smd_abi_version(void);
+/* 16 hex digits: a hash of the sources, headers and compiler flags this binary was built from (build.py source_id()).  The
+ * host refuses to run a library whose id differs from its tree's (a stale .so next to edited sources). */
+const char* smd_build_id(void);
 
 /* ---- model description: the kwargs of train_ncsn.py:321-326 + data shape ---------------------- */
 typedef struct smd_model_desc {
@@ -119,6 +122,14 @@ int smd_engine_forward_level(smd_engine* e, const float* x, const int32_t* level
 int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labels, const float* eps_in,
                              uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset,
                              float inv_global_count, int stage, void* stream);
+/* jax.value_and_grad over an ARBITRARY objective (train_ncsn.py:279-283, `objective` is any callable of the model's output):
+ * smd_engine_forward_train = model(x, noise_level) in the bound TRAINING workspace, every activation the backward needs saved
+ * (eps_out [B][S][C] fp32, nullable: smd_engine_pred); smd_engine_backward_from = the backward pass of that forward from
+ * dpred = d objective / d eps_hat ([B][S][C] fp32), parameter gradients WRITTEN to the bound gradient buffer.  stage as in
+ * smd_engine_loss_backward (0 everything, 1 output stage, 2 the rest; dpred is read by stages 0 and 1).  The host binds the pair
+ * to torch autograd (ops.py smd_amd::eps_forward_train), so train_step accepts objectives other than the two fused ones. */
+int smd_engine_forward_train(smd_engine* e, const float* x, const float* noise_level, float* eps_out, void* stream);
+int smd_engine_backward_from(smd_engine* e, const float* dpred, int stage, void* stream);
 /* continuous_noise=False (utils/losses.py:272-286; option "label_min" = 0): labels are drawn in [0, T) and label 0 takes
  * a real uniform used_alpha in [alphas_prod[T], 1).  used_alphas ([B] device floats, or NULL) replaces the label -> alpha
  * lookup of the following smd_engine_loss_backward calls (parity mode: the reference's own jax.random.uniform draws). */
@@ -188,6 +199,13 @@ int smd_engine_init_state(smd_engine* e, float* x, uint32_t seed_lo, uint32_t se
 /* explicit initial state (parity mode / infill / interpolation): refreshes the bf16 network input */
 int smd_engine_load_state(smd_engine* e, const float* x, void* stream);
 int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream);
+/* The two halves of that iteration, for a software pipeline over independent chains (the batch of diffusion_dynamics is a set of
+ * independent samples): part 1 = the network's stem (models/ncsn.py:152-171: in_proj .. up projection; it reads the state left by
+ * the previous reverse update and does not depend on t), part 2 = the output stage (models/ncsn.py:173-178) + the fused reverse
+ * update (utils/ebm_utils.py:327-394), which advances *t_ptr.  part 1 then part 2 on one stream == smd_engine_sample_step.  The
+ * host runs chain A as (2, 1) and chain B as (1, 2) on two streams inside one captured graph, so one chain's latency-bound
+ * encoder kernels always sit beside the other's 2048-wide GEMMs (two free-running chains drift INTO phase: DESIGN.md section 5). */
+int smd_engine_sample_step_part(smd_engine* e, const smd_sample_io* io, int part, void* stream);
 
 /* One Langevin update of annealed_langevin_dynamics / consistent_langevin_dynamics (utils/ebm_utils.py:131-164, 231-253):
  *   next = x + alpha * grad + noise_coef * z;  with infill: next = next (1 - mask) + (infill_samples + infill_sigma * zi) mask.
@@ -399,6 +417,17 @@ int smd_ddpm_reverse_step(float* x, const float* eps_hat, int B, int S, int C, c
                           const int32_t* t_ptr, const float* z_in, uint32_t seed_lo, uint32_t seed_hi,
                           uint32_t sample_offset, float* metrics_partial, float* collection,
                           const int32_t* slot_table, void* stream);
+/* A HIP stream (returned as void*) whose kernels are dispatched only to the XCDs set in xcd_mask (bit x = XCD x of the 8):
+ * hipExtStreamCreateWithCUMask with the CUs of those XCDs.  The host walks the two concurrent half-batch sampling chains
+ * (utils/ebm_utils.py:399-401 over two independent halves of the batch) on streams of XCDs 0-3 and 4-7: each chain's 128-tile
+ * GEMMs then own 128 CUs and four private L2s, whatever the other chain is doing.  layout 0 is the mapping of mask bits to
+ * XCDs the driver implements (bit i -> XCD i % 8, tools/cumask_probe.hip); layout 1 (bit i -> XCD i / 32) exists for that
+ * probe only.  The stream belongs to the caller: smd_stream_destroy. */
+int smd_stream_create_xcd_mask(uint32_t xcd_mask, int layout, void** stream_out);
+int smd_stream_destroy(void* stream);
+/* lab probe: `blocks` one-wave workgroups spin for ~spin_us; out[8 * b + ..] = XCC id, HW_ID, shader-clock ticks (2 words),
+ * 100 MHz ticks (2 words), start time in 100 MHz ticks (2 words) -- where a stream runs and at which clock */
+int smd_probe_clock(uint32_t* out, int blocks, int spin_us, void* stream);
 /* lane-level probe of ds_read_b64_tr_b16 (debug): out[64][4] = values read from a 2 KiB linear image */
 int smd_probe_tr_read(const smd_bf16* image_1024, smd_bf16* out_256, void* stream);
 

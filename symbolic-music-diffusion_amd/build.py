@@ -5,7 +5,9 @@ to the GPU box.  Usage: ``python -m smd_amd.build`` or ``build_library()``.
 """
 from __future__ import annotations
 
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -54,45 +56,106 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
-def _newest_input() -> float:
-    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return max(os.path.getmtime(f) for f in files)
+# ---- build identity: a hash of what the library is built FROM (sources, headers, flags), embedded in the .so as the string
+# "SMD_BUILD_ID=<16 hex>" and returned by smd_build_id().  Staleness is decided by comparing that id with the id of the tree --
+# never by file times, which an rsync / clone / snapshot can put in any order.
+_ID_RE = re.compile(rb"SMD_BUILD_ID=([0-9a-f]{16})")
+
+
+def _read(path: str) -> bytes:
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def _headers_digest() -> bytes:
+    h = hashlib.sha256()
+    for name in HEADERS:
+        h.update(name.encode() + b"\0" + _read(os.path.join(CSRC, name)))
+    return h.digest()
+
+
+def _object_id(src: str, hdr: bytes) -> str:
+    h = hashlib.sha256()
+    h.update(hdr + _read(os.path.join(CSRC, src)) + " ".join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
+    return h.hexdigest()[:12]
+
+
+def source_id() -> str:
+    """The id a library built from the current tree (and the current SMD_* build environment) carries."""
+    hdr = _headers_digest()
+    h = hashlib.sha256()
+    for src in SOURCES:
+        h.update(src.encode() + _object_id(src, hdr).encode())
+    return h.hexdigest()[:16]
+
+
+def built_id(path: str = None) -> str:
+    """The id embedded in an existing library ('' when the file is missing or carries none), read without loading it."""
+    path = LIB_PATH if path is None else path
+    if not os.path.exists(path):
+        return ""
+    m = _ID_RE.search(_read(path))
+    return m.group(1).decode() if m else ""
 
 
 def is_stale() -> bool:
-    return not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest_input()
+    return built_id() != source_id()
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
-    if not force and not is_stale():
+    """Compiles what is missing and links; returns the library path.  ``build_library.last`` says what happened:
+    'reused' (the library's embedded id matches the tree), 'linked' (objects reused, library re-linked) or 'compiled N'."""
+    sid = source_id()
+    if not force and built_id() == sid:
+        build_library.last = "reused"
+        if verbose:
+            print(f"[smd_amd.build] {LIB_PATH} is current (build id {sid}): reused", file=sys.stderr)
         return LIB_PATH
     hipcc = find_hipcc()
     objdir = os.path.join(CSRC, "build" + _SUFFIX)
     os.makedirs(objdir, exist_ok=True)
-    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr = _headers_digest()
+    compiled = []
 
     def compile_one(src: str) -> str:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        srcp = os.path.join(CSRC, src)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(srcp), hdr_time):
+        stem = src.replace(".hip", "")
+        obj = os.path.join(objdir, f"{stem}.{_object_id(src, hdr)}.o")       # content-addressed: no file times involved
+        if not force and os.path.exists(obj):
             return obj
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", srcp, "-o", obj]
+        for old in os.listdir(objdir):
+            if old.startswith(stem + ".") and old.endswith(".o"):
+                os.remove(os.path.join(objdir, old))
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj + ".tmp"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        os.replace(obj + ".tmp", obj)
+        compiled.append(src)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
+    idsrc = os.path.join(objdir, "build_id.cpp")
+    with open(idsrc, "w") as f:
+        f.write('extern "C" const char* smd_build_id(void) { static const char id[] = "SMD_BUILD_ID=%s"; return id + 13; }\n' % sid)
+    idobj = os.path.join(objdir, "build_id.o")
+    r = subprocess.run([hipcc, "-O1", "-fPIC", "-c", idsrc, "-o", idobj], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on build_id.cpp:\n{r.stdout}\n{r.stderr}")
     tmp = LIB_PATH + ".tmp"
-    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs],
+    r = subprocess.run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp, *objs, idobj],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(tmp, LIB_PATH)
+    build_library.last = f"compiled {len(compiled)}" if compiled else "linked"
     if verbose:
-        print(f"[smd_amd.build] built {LIB_PATH}", file=sys.stderr)
+        print(f"[smd_amd.build] built {LIB_PATH} (build id {sid}; {len(compiled)} of {len(SOURCES)} translation units compiled: "
+              f"{', '.join(compiled) or 'none'})", file=sys.stderr)
     return LIB_PATH
+
+
+build_library.last = ""
 
 
 if __name__ == "__main__":

@@ -89,6 +89,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   if (std::string(key) == "group_wgrad") { e->impl.group_wgrad = value; return 0; }
   if (std::string(key) == "fused_encoder") { e->impl.fused_encoder = value; return 0; }
   if (std::string(key) == "trunk_bf16") { e->impl.trunk_bf16 = value; return 0; }
+  if (std::string(key) == "sample_split") { e->impl.sample_split = value < 0 ? 0 : value; return 0; }
   if (std::string(key) == "nt256_min_tiles") { e->impl.nt256_min_tiles = value; return 0; }
   if (std::string(key) == "grad_memset") { e->impl.grad_memset = value; return 0; }
   if (std::string(key) == "tail_on_main") { e->impl.tail_on_main = value ? 1 : 0; return 0; }
@@ -135,6 +136,14 @@ int smd_engine_loss_backward(smd_engine* e, const float* x0, const int32_t* labe
   NEED(e);
   return e->impl.loss_backward(x0, labels, eps_in, seed_lo, seed_hi, sample_offset, inv_global_count, stage, S(stream));
 }
+int smd_engine_forward_train(smd_engine* e, const float* x, const float* noise_level, float* eps_out, void* stream) {
+  NEED(e);
+  return e->impl.forward_train(x, noise_level, eps_out, S(stream));
+}
+int smd_engine_backward_from(smd_engine* e, const float* dpred, int stage, void* stream) {
+  NEED(e);
+  return e->impl.backward_from(dpred, stage, S(stream));
+}
 int smd_engine_set_used_alphas(smd_engine* e, const float* used_alphas) {
   NEED(e);
   e->impl.set_used_alphas(used_alphas);
@@ -180,7 +189,7 @@ int smd_engine_load_state(smd_engine* e, const float* x, void* stream) {
   NEED(e);
   return e->impl.load_state(x, S(stream));
 }
-int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream) {
+static int sample_step_part(smd_engine* e, const smd_sample_io* io, int part, void* stream) {
   NEED(e);
   SMD_ARG_CHECK(io, "sample_step: null io");
   SampleStepIO s;
@@ -190,7 +199,12 @@ int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream)
   s.slot_table = io->slot_table;
   s.tf_noise_keys = io->tf_noise_keys; s.tf_infill_keys = io->tf_infill_keys; s.tf_n_total = io->tf_n_total; s.tf_t0 = io->tf_t0;
   s.key_ptr = io->key_ptr;
-  return e->impl.sample_step(s, S(stream));
+  return e->impl.sample_step(s, S(stream), part);
+}
+int smd_engine_sample_step(smd_engine* e, const smd_sample_io* io, void* stream) { return sample_step_part(e, io, 0, stream); }
+int smd_engine_sample_step_part(smd_engine* e, const smd_sample_io* io, int part, void* stream) {
+  SMD_ARG_CHECK(part == 1 || part == 2, "smd_engine_sample_step_part: part=%d (1 stem, 2 output stage + reverse update)", part);
+  return sample_step_part(e, io, part, stream);
 }
 
 // ------------------------------------------------------------------ single kernels
@@ -410,5 +424,60 @@ int smd_ddpm_reverse_step(float* x, const float* eps_hat, int Bn, int Sn, int C,
 }
 
 int smd_probe_tr_read(const smd_bf16* image, smd_bf16* out, void* stream) { return launch_probe_tr_read(B(image), B(out), S(stream)); }
+
+// ---- streams pinned to a subset of the XCDs (the two sampling chains: one half of the chip each)
+int smd_stream_create_xcd_mask(uint32_t xcd_mask, int layout, void** stream_out) {
+  SMD_ARG_CHECK(stream_out, "smd_stream_create_xcd_mask: null argument");
+  SMD_ARG_CHECK((xcd_mask & 0xFFu) != 0 && (xcd_mask >> 8) == 0, "smd_stream_create_xcd_mask: xcd_mask=0x%x must select 1..8 of the 8 XCDs", xcd_mask);
+  SMD_ARG_CHECK(layout == 0 || layout == 1, "smd_stream_create_xcd_mask: layout=%d (0 interleaved, 1 blocked)", layout);
+  // 256 mask bits, one per CU.  layout 0: bit i belongs to XCD i % 8 (the KFD walks the mask round-robin over the XCCs);
+  // layout 1: bit i belongs to XCD i / 32 (lab only: tools/cumask_probe decides which one the driver implements)
+  uint32_t words[8];
+  for (int w = 0; w < 8; ++w) {
+    uint32_t v = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int i = w * 32 + b;
+      const int xcd = layout == 0 ? (i & 7) : (i >> 5);
+      if ((xcd_mask >> xcd) & 1u) v |= 1u << b;
+    }
+    words[w] = v;
+  }
+  hipStream_t st = nullptr;
+  const hipError_t err = hipExtStreamCreateWithCUMask(&st, 8, words);
+  if (err != hipSuccess) { smd_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(err)); return (int)err; }
+  *stream_out = reinterpret_cast<void*>(st);
+  return 0;
+}
+int smd_stream_destroy(void* stream) {
+  SMD_ARG_CHECK(stream, "smd_stream_destroy: null stream");
+  const hipError_t err = hipStreamDestroy(S(stream));
+  if (err != hipSuccess) { smd_set_error("hipStreamDestroy: %s", hipGetErrorString(err)); return (int)err; }
+  return 0;
+}
+
+// lab probe: where a one-wave kernel runs and the shader clock it sees.  out[0] = XCC id, out[1] = HW_ID, out[2..3] = s_memtime
+// ticks (shader cycles) and out[4..5] = s_memrealtime ticks (100 MHz) spent spinning for ~spin_us
+__global__ __launch_bounds__(64) void probe_clock_kernel(uint32_t* __restrict__ out, int spin_us) {
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+  const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);         // HW_REG_HW_ID
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t c0 = __builtin_amdgcn_s_memtime();
+  uint64_t r1 = r0;
+  while (r1 - r0 < (uint64_t)spin_us * 100) { __builtin_amdgcn_s_sleep(4); r1 = __builtin_amdgcn_s_memrealtime(); }
+  const uint64_t c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    uint32_t* o = out + 8 * blockIdx.x;
+    o[0] = xcc; o[1] = hw;
+    o[2] = (uint32_t)(c1 - c0); o[3] = (uint32_t)((c1 - c0) >> 32);
+    o[4] = (uint32_t)(r1 - r0); o[5] = (uint32_t)((r1 - r0) >> 32);
+    o[6] = (uint32_t)r0; o[7] = (uint32_t)(r0 >> 32);
+  }
+}
+int smd_probe_clock(uint32_t* out, int blocks, int spin_us, void* stream) {
+  SMD_ARG_CHECK(out && blocks > 0 && spin_us >= 0, "smd_probe_clock: bad argument");
+  hipLaunchKernelGGL(probe_clock_kernel, dim3(blocks), dim3(64), 0, S(stream), out, spin_us);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
 
 }  // extern "C"

@@ -121,7 +121,9 @@ class SmdEngine {
   int wait_grad_bucket(int b, hipStream_t s);      // `s` waits for bucket b's event (no-op for the last bucket / events off)
   int join_update(hipStream_t st);      // make `st` wait for a deferred output-stage update (no-op when none is pending)
   int prepare_sampler(hipStream_t st);                       // FiLM tables for every timestep
-  int sample_step(const SampleStepIO& io, hipStream_t st);   // eps-net forward + fused reverse step
+  int forward_train(const float* x, const float* noise_level, float* eps_out, hipStream_t st);   // model(x, cond), activations saved
+  int backward_from(const float* dpred, int stage, hipStream_t st);                                 // backward of that pass from d/d eps_hat
+  int sample_step(const SampleStepIO& io, hipStream_t st, int part = 0);   // eps-net forward + fused reverse step
   int init_state(float* x, uint32_t seed_lo, uint32_t seed_hi, uint32_t sample_offset, hipStream_t st);
   int load_state(const float* x, hipStream_t st);            // explicit state -> bf16 network input
   // device pointers of a few internals (tests / metrics)
@@ -168,6 +170,7 @@ class SmdEngine {
   // oracle, gradient parity unchanged (5.7e-3); sample step +9.6 %, train step +2.2 %.
   int trunk_bf16 = 2;      // 0: fp32 trunk everywhere; 1: bf16 in inference workspaces only; 2: training too (default)
   bool trunk_bf16_on() const { return d_.mlp_dims % 8 == 0 && (training_ ? trunk_bf16 == 2 : trunk_bf16 >= 1); }
+  int sample_split = 0;        // split sampler passes (sample_step part 1 / 2): half-blocks of the output stage that belong to part 1
   int nt256_min_tiles = 0; // > 0: Dense layers take the 256x256 GEMM from this many tiles up (concurrent sampling chains: 128)
   int grad_memset = 2;     // 0 never, 1 always, 2 (default): only with the tr_path = 0 fallback wgrads
   int tail_on_main = 1;    // the last grouped wgrad launch of a step runs on the caller's stream (which would idle) while
@@ -196,7 +199,7 @@ class SmdEngine {
   int nblocks() const { return d_.arch == 0 ? d_.num_mlp_layers : d_.num_layers; }
   int rows() const { return batch_ * d_.seq_len; }
   void build_layout();
-  int run_network(const int* t_ptr, hipStream_t st);          // x_bf16 (+ s or table row) -> pred
+  int run_network(const int* t_ptr, hipStream_t st, int part = 0);          // x_bf16 (+ s or table row) -> pred
   int backward_head(hipStream_t st);
   int backward_stem(hipStream_t st);
   int dense_fwd(const DenseP& p, const bf16_t* A, int lda, int M, GemmEpilogue ep, hipStream_t st);
@@ -254,6 +257,8 @@ class SmdEngine {
   hipEvent_t head_done_ev_ = nullptr;          // recorded behind it (owned; not from the recycled pool)
   std::vector<hipEvent_t> bucket_ev_;          // dp_layer_events: one per early stem bucket (owned)
   int buckets_recorded_ = 0;
+  hipEvent_t stem_done_ev_ = nullptr;          // dp_layer_events: behind the whole backward (fallback of wait_grad_bucket; owned)
+  bool stem_done_valid_ = false;
 
   struct Work {
     // inputs / outputs of the network

@@ -37,6 +37,7 @@ SmdEngine::~SmdEngine() {
   if (side_) (void)hipStreamSynchronize(side_);        // a deferred update may still be reading the caller's buffers
   if (head_done_ev_) (void)hipEventDestroy(head_done_ev_);
   for (hipEvent_t e : bucket_ev_) (void)hipEventDestroy(e);
+  if (stem_done_ev_) (void)hipEventDestroy(stem_done_ev_);
   for (hipEvent_t e : events_) (void)hipEventDestroy(e);
   if (side_) (void)hipStreamDestroy(side_);
 }
@@ -233,7 +234,9 @@ void SmdEngine::build_opt_tables() {
     std::vector<std::pair<int64_t, int64_t>> dense_ranges;
     for (const DenseP* p : all_dense_) {
       if (p->w_off < lo || p->w_off >= hi) continue;
-      if (t.n_dense == SMD_OPT_DENSE_MAX || t.n_flat + 2 >= SMD_OPT_FLAT_MAX) { opt_fused_ok_ = false; return; }   // very deep DenseDDPM: three-pass fallback
+      // a very deep DenseDDPM: three-pass fallback.  Every user of the tables (optimizer_step, loss_backward's early norm) tests
+      // opt_fused_ok_ first, so the tables may stay half built; the flat runs are counted by add_flat below
+      if (t.n_dense == SMD_OPT_DENSE_MAX) { opt_fused_ok_ = false; return; }
       OptDense& e = t.d[t.n_dense++];
       e.w_off = (uint32_t)p->w_off; e.K = (uint32_t)p->K; e.N = (uint32_t)p->N;
       e.W_off = (uint32_t)p->W_off; e.ldw = (uint32_t)p->Np; e.Wt_off = (uint32_t)p->Wt_off; e.ldwt = (uint32_t)p->Kp;
@@ -427,7 +430,14 @@ int SmdEngine::grad_bucket(int b, int64_t* off, int64_t* len) const {
 
 int SmdEngine::wait_grad_bucket(int b, hipStream_t s) {
   SMD_ARG_CHECK(b >= 0 && b < num_grad_buckets(), "wait_grad_bucket: index %d of %d", b, num_grad_buckets());
-  if (b >= buckets_recorded_) return 0;                        // the last bucket, or events off: complete in the caller's stream order
+  if (b >= buckets_recorded_) {
+    // no per-layer event for this bucket (the last bucket; or an option combination under which the stem backward records
+    // none, e.g. group_wgrad != 2): it is final when the whole backward is -- the event loss_backward leaves behind it
+    if (!stem_done_ev_ || !stem_done_valid_) return 0;           // nothing recorded: the caller orders the stream itself
+    hipError_t e0 = hipStreamWaitEvent(s, stem_done_ev_, 0);
+    if (e0 != hipSuccess) { smd_set_error("wait_grad_bucket: %s", hipGetErrorString(e0)); return (int)e0; }
+    return 0;
+  }
   hipError_t e = hipStreamWaitEvent(s, bucket_ev_[b], 0);
   if (e != hipSuccess) { smd_set_error("wait_grad_bucket: %s", hipGetErrorString(e)); return (int)e; }
   return 0;
@@ -485,8 +495,12 @@ int SmdEngine::dense_bwd(const DenseP& p, const bf16_t* X, int ldx, const bf16_t
 }
 
 // ------------------------------------------------------------------ forward
-int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
+// part 0: the whole network; 1: the stem only (x_bf16 -> trunk input: in_proj, encoder layers, final norm, up projection --
+// nothing in it depends on the noise level); 2: the output stage only (DenseResBlocks with their FiLM rows, output norm +
+// Dense).  The split passes serve the sampler's software pipeline (sample_step): one chain's stem beside another's head.
+int SmdEngine::run_network(const int* t_ptr, hipStream_t st, int part) {
   SMD_ARG_CHECK(params_ && wpack_ && batch_ > 0, "run_network: engine not bound");
+  SMD_ARG_CHECK(part == 0 || (part >= 1 && part <= 2 && !training_ && t_ptr), "run_network: split passes belong to the table-driven sampler");
   const int S = d_.seq_len, C = d_.data_channels, E = d_.embed_channels, M = d_.mlp_dims, F = d_.film_channels;
   const int R = rows(), B = batch_, K = nblocks();
   const bool tr = training_ != 0;
@@ -522,7 +536,9 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
   const bool tb = trunk_bf16_on();
   auto ybk = [&](int k) { return reinterpret_cast<bf16_t*>(W.y[tr ? k : 0]); };
   bf16_t* yb = ybk(0);
-  if (d_.arch == 0) {
+  if (part == 2) {
+    // output stage only: the trunk input is where an earlier stem pass of this handle left it
+  } else if (d_.arch == 0) {
     {  // in_proj + positional encoding (models/ncsn.py:152-157)
       GemmEpilogue ep;
       ep.res_f32 = W.pe; ep.ld_res = E; ep.res_row_mod = S;
@@ -603,6 +619,7 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
     RC(dense_fwd(in_proj_, W.x_bf16, Cp_, R, ep, st));
     RC(join_update(st));
   }
+  if (part == 1 && sample_split <= 0) return 0;
 
   // DenseResBlocks (models/shared.py:61-75) each with its own FiLM generator (models/ncsn.py:47-61,
   // 173-175 / 130-132).  Per-sample noise levels generate scale/shift here; the sampler reads the
@@ -627,11 +644,14 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
     }
     w8_dirty_ = false;
   }
+  // split passes: part 1 also runs the first `sample_split` half-blocks (LayerNorm + Dense) of the output stage, part 2 the rest
+  auto runs_hb = [&](int hb) { return part == 0 || (part == 1 ? hb < sample_split : hb >= sample_split); };
   for (int k = 0; k < K; ++k) {
     const int i = tr ? k : 0;
     const FilmResP& b = blk_[k];
     float* y_in = tr ? W.y[k] : W.y[0];
     float* y_out = tr ? W.y[k + 1] : W.y[0];
+    if (!runs_hb(2 * k) && !runs_hb(2 * k + 1)) continue;
     const float* scale;
     const int ld_film = 2 * M;
     if (t_ptr) {
@@ -653,32 +673,41 @@ int SmdEngine::run_network(const int* t_ptr, hipStream_t st) {
       // e4m3 forward GEMMs: the LayerNorm writes the A operand as e4m3 + row scales (and, when training, the bf16 copy
       // the weight gradient contracts), the weights were quantised per output row above
       const size_t wo = (size_t)k * 2 * M * M, so = (size_t)k * 2 * M;
-      if (tb) { ln.x = nullptr; ln.x_bf16 = ybk(k); } else ln.x = y_in;
-      ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off);
-      ln.out = tr ? W.ya1[i] : nullptr; ln.out_f8 = W.ya1_f8[i]; ln.out_scale = W.sa1[i];
-      RC(launch_layernorm_fwd(ln, st));
-      { GemmEpilogue ep; ep.bias = P(b.r1.b_off); ep.out_bf16 = W.o1[i]; ep.ld_outb = M;
-        RC(launch_gemm_nt256_fp8(W.ya1_f8[i], M, W.sa1[i], W.w8 + wo, M, W.w8s + so, R, M, M, ep, st)); }
-      ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off);
-      ln.out = tr ? W.ya2[i] : nullptr; ln.out_f8 = W.ya2_f8[i]; ln.out_scale = W.sa2[i];
-      RC(launch_layernorm_fwd(ln, st));
-      { GemmEpilogue ep; ep.bias = P(b.r2.b_off);
-        if (tb) { ep.res_bf16 = ybk(k); ep.ld_resb = M; ep.out_bf16 = ybk(k + 1); ep.ld_outb = M; }
-        else { ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M; }
-        RC(launch_gemm_nt256_fp8(W.ya2_f8[i], M, W.sa2[i], W.w8 + wo + (size_t)M * M, M, W.w8s + so + M, R, M, M, ep, st)); }
+      if (runs_hb(2 * k)) {
+        if (tb) { ln.x = nullptr; ln.x_bf16 = ybk(k); } else ln.x = y_in;
+        ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off);
+        ln.out = tr ? W.ya1[i] : nullptr; ln.out_f8 = W.ya1_f8[i]; ln.out_scale = W.sa1[i];
+        RC(launch_layernorm_fwd(ln, st));
+        { GemmEpilogue ep; ep.bias = P(b.r1.b_off); ep.out_bf16 = W.o1[i]; ep.ld_outb = M;
+          RC(launch_gemm_nt256_fp8(W.ya1_f8[i], M, W.sa1[i], W.w8 + wo, M, W.w8s + so, R, M, M, ep, st)); }
+      }
+      if (runs_hb(2 * k + 1)) {
+        ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off);
+        ln.out = tr ? W.ya2[i] : nullptr; ln.out_f8 = W.ya2_f8[i]; ln.out_scale = W.sa2[i];
+        RC(launch_layernorm_fwd(ln, st));
+        { GemmEpilogue ep; ep.bias = P(b.r2.b_off);
+          if (tb) { ep.res_bf16 = ybk(k); ep.ld_resb = M; ep.out_bf16 = ybk(k + 1); ep.ld_outb = M; }
+          else { ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M; }
+          RC(launch_gemm_nt256_fp8(W.ya2_f8[i], M, W.sa2[i], W.w8 + wo + (size_t)M * M, M, W.w8s + so + M, R, M, M, ep, st)); }
+      }
       continue;
     }
-    if (tb) { ln.x = nullptr; ln.x_bf16 = ybk(k); } else ln.x = y_in;
-    ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off); ln.out = W.ya1[i];
-    RC(launch_layernorm_fwd(ln, st));
-    { GemmEpilogue ep; ep.out_bf16 = W.o1[i]; ep.ld_outb = M; RC(dense_fwd(b.r1, W.ya1[i], M, R, ep, st)); }
-    ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off); ln.out = W.ya2[i];
-    RC(launch_layernorm_fwd(ln, st));
-    { GemmEpilogue ep;
-      if (tb) { ep.res_bf16 = ybk(k); ep.ld_resb = M; ep.out_bf16 = ybk(k + 1); ep.ld_outb = M; }
-      else { ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M; }
-      RC(dense_fwd(b.r2, W.ya2[i], M, R, ep, st)); }
+    if (runs_hb(2 * k)) {
+      if (tb) { ln.x = nullptr; ln.x_bf16 = ybk(k); } else ln.x = y_in;
+      ln.gamma = P(b.ln1.g_off); ln.beta = P(b.ln1.b_off); ln.out = W.ya1[i];
+      RC(launch_layernorm_fwd(ln, st));
+      { GemmEpilogue ep; ep.out_bf16 = W.o1[i]; ep.ld_outb = M; RC(dense_fwd(b.r1, W.ya1[i], M, R, ep, st)); }
+    }
+    if (runs_hb(2 * k + 1)) {
+      ln.x = nullptr; ln.x_bf16 = W.o1[i]; ln.gamma = P(b.ln2.g_off); ln.beta = P(b.ln2.b_off); ln.out = W.ya2[i];
+      RC(launch_layernorm_fwd(ln, st));
+      { GemmEpilogue ep;
+        if (tb) { ep.res_bf16 = ybk(k); ep.ld_resb = M; ep.out_bf16 = ybk(k + 1); ep.ld_outb = M; }
+        else { ep.res_f32 = y_in; ep.ld_res = M; ep.out_f32 = y_out; ep.ld_out = M; }
+        RC(dense_fwd(b.r2, W.ya2[i], M, R, ep, st)); }
+    }
   }
+  if (part == 1) return 0;
   {  // models/ncsn.py:177-178 / 133-134
     LnArgs ln;
     if (tb) ln.x_bf16 = ybk(K); else ln.x = tr ? W.y[K] : W.y[0];
@@ -976,6 +1005,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       // this layer's parameter gradients are final once its two LayerNorm reductions (main stream) and its grouped weight
       // gradients (side stream) have run: one event behind both
       RC(flush_ln_reduce(st));
+      if (!pending256_.empty()) RC(flush_pending256(st));      // a 256-wide encoder wgrad (embed_channels % 256 == 0) parked for grouping
       const int b = d_.num_layers - 1 - l;
       while ((int)bucket_ev_.size() <= b) {
         hipEvent_t ev = nullptr;
@@ -1077,7 +1107,56 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     RC(flush_ln_reduce(st));                       // one launch for every pending LayerNorm dgamma/dbeta
     RC(flush_grouped_wgrads(st, tail_on_main != 0));
   }
-  return join_side(st);      // every gradient is complete on `st` when this returns (stage 1: the output stage)
+  RC(join_side(st));         // every gradient is complete on `st` when this returns (stage 1: the output stage)
+  stem_done_valid_ = false;
+  if (dp_layer_events && (stage == 0 || stage == 2)) {
+    // what smd_engine_wait_grad_bucket falls back to for a bucket without a per-layer event
+    if (!stem_done_ev_) SMD_ARG_CHECK(hipEventCreateWithFlags(&stem_done_ev_, hipEventDisableTiming) == hipSuccess, "loss_backward: cannot create an event");
+    hipError_t e = hipEventRecord(stem_done_ev_, st);
+    if (e != hipSuccess) { smd_set_error("loss_backward: event: %s", hipGetErrorString(e)); return (int)e; }
+    stem_done_valid_ = true;
+  }
+  return 0;
+}
+
+// The two halves of jax.value_and_grad over an ARBITRARY objective (train_ncsn.py:279-283): model(x, noise_level) in the training
+// workspace with every activation the backward needs saved, then the backward pass from d objective / d eps_hat.
+int SmdEngine::forward_train(const float* x, const float* noise_level, float* eps_out, hipStream_t st) {
+  SMD_ARG_CHECK(x && noise_level, "forward_train: null pointer");
+  SMD_ARG_CHECK(training_ && batch_ > 0, "forward_train: bind a training workspace first");
+  const int R = rows(), C = d_.data_channels;
+  RC(launch_cast_pad_bf16(x, R, C, W.x_bf16, Cp_, st));
+  hipError_t e = hipMemcpyAsync(W.s, noise_level, sizeof(float) * batch_, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { smd_set_error("forward_train: memcpy: %s", hipGetErrorString(e)); return (int)e; }
+  RC(run_network(nullptr, st));
+  if (!eps_out) return 0;
+  e = hipMemcpyAsync(eps_out, W.pred, sizeof(float) * (size_t)R * C, hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) { smd_set_error("forward_train: memcpy: %s", hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+
+int SmdEngine::backward_from(const float* dpred, int stage, hipStream_t st) {
+  SMD_ARG_CHECK(training_ && grads_ && batch_ > 0, "backward_from: bind a training workspace and the optimiser state first");
+  SMD_ARG_CHECK(stage >= 0 && stage <= 2, "backward_from: stage=%d", stage);
+  SMD_ARG_CHECK(stage == 2 || dpred, "backward_from: null gradient");
+  if (stage != 2) {
+    const bool need_memset = grad_memset == 1 || (grad_memset == 2 && !(tr_path == 1));
+    if (need_memset) {
+      hipError_t e = hipMemsetAsync(grads_, 0, sizeof(float) * (size_t)n_params_, st);
+      if (e != hipSuccess) { smd_set_error("backward_from: memset: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    RC(launch_cast_pad_bf16(dpred, rows(), d_.data_channels, W.dpred, Cp_, st));
+    RC(backward_head(st));
+    head_norm_ready_ = false;
+    if (stage == 1) RC(flush_ln_reduce(st));
+    RC(flush_grouped_wgrads(st));
+  }
+  if (stage != 1) {
+    RC(backward_stem(st));
+    RC(flush_ln_reduce(st));
+    RC(flush_grouped_wgrads(st, tail_on_main != 0));
+  }
+  return join_side(st);
 }
 
 int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {
@@ -1160,10 +1239,12 @@ int SmdEngine::load_state(const float* x, hipStream_t st) {
   return launch_cast_pad_bf16(x, rows(), d_.data_channels, W.x_bf16, Cp_, st);
 }
 
-int SmdEngine::sample_step(const SampleStepIO& io, hipStream_t st) {
+int SmdEngine::sample_step(const SampleStepIO& io, hipStream_t st, int part) {
   SMD_ARG_CHECK(io.x && io.t_ptr, "sample_step: null state / t pointer");
   SMD_ARG_CHECK(!training_ && coef_ && film_tables_, "sample_step: bind an inference workspace and the schedule tables first");
-  RC(run_network(io.t_ptr, st));
+  SMD_ARG_CHECK(part >= 0 && part <= 2, "sample_step: part=%d (0 whole step, 1 stem, 2 output stage + reverse update)", part);
+  RC(run_network(io.t_ptr, st, part));
+  if (part == 1) return 0;
   ReverseStepArgs a;
   a.x = io.x; a.eps_hat = W.pred;
   a.B = batch_; a.S = d_.seq_len; a.C = d_.data_channels; a.Cp = Cp_; a.T = d_.num_timesteps;

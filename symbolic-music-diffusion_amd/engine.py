@@ -120,6 +120,7 @@ class Engine:
             _lib.check(self.L.smd_engine_set_option(h, k.strip().encode(), int(v)), f"SMD_ENGINE_OPTS {kv}")
         self._label_min = 1
         self._loss_kind = 0
+        self.generation = 0          # bumped by whatever invalidates a captured step of this handle: bind, schedule, options
         self.grads = self.m = self.v = self.ema = None
         self.step_counter = None
         self.metrics = None
@@ -208,11 +209,21 @@ class Engine:
     def _sync_fp8_weights(self) -> None:
         """fp8 mode: tell this handle when the shared bf16 operand pack was refreshed through another handle."""
         if self.cfg.dtype == "fp8" and self._wseen != self._wstate["ver"]:
+            self._join_foreign_pending()
             _lib.check(self.L.smd_engine_set_option(self.h, b"w8_dirty", 1), "set_option w8_dirty")
             self._wseen = self._wstate["ver"]
 
     def set_option(self, key: str, value: int) -> None:
         _lib.check(self.L.smd_engine_set_option(self.h, key.encode(), int(value)), "set_option")
+        if key != "w8_dirty":
+            self.generation += 1
+
+    def _join_foreign_pending(self) -> None:
+        """A deferred output-stage update of ANOTHER handle on these parameters (opt_overlap bit 0) must be complete before
+        this handle reads them; this handle's own deferred update is joined inside the library."""
+        p = self._wstate.get("pending")
+        if p is not None and p is not self:
+            self._join_pending()
 
     # ------------------------------------------------------------------ binding
     def set_schedule(self, betas: np.ndarray, with_sampler: bool = True) -> None:
@@ -220,6 +231,7 @@ class Engine:
         if len(betas) != self.cfg.num_timesteps:
             raise ValueError(f"schedule has {len(betas)} steps, model built for {self.cfg.num_timesteps}")
         self.betas = betas
+        self.generation += 1
         coef = _sched.reverse_coefficient_table(betas)
         ape = np.concatenate([np.ones(1, np.float32), _sched.alphas_cumprod(betas)])
         dev = self.device
@@ -248,6 +260,7 @@ class Engine:
                  slot=torch.full((T,), -1, dtype=torch.int32, device=dev),
                  film=torch.zeros(int(self.L.smd_engine_film_table_floats(self.h)), dtype=torch.float32, device=dev))
         self._sched_tensors, self.betas = t, None
+        self.generation += 1
         _lib.check(self.L.smd_engine_bind_schedule(self.h, _ptr(t["coef"]), _ptr(t["sqrt_ap"]), _ptr(t["ape"]), _ptr(t["film"])),
                    "bind_schedule")
         self.prepare_sampler()
@@ -263,6 +276,7 @@ class Engine:
             _lib.check(self.L.smd_engine_bind_workspace(self.h, _ptr(self.workspace), nbytes, batch, int(training),
                                                         _stream()), "bind_workspace")
         self.batch, self.training = batch, training
+        self.generation += 1
 
     def enable_training(self, ema: bool) -> None:
         if self.grads is not None:
@@ -317,11 +331,42 @@ class Engine:
         _lib.check(self.L.smd_engine_set_used_alphas(self.h, _ptr(used_alphas)), "set_used_alphas")
         gb = B if global_batch is None else global_batch
         inv = 1.0 / (gb * float(np.prod(self.cfg.sample_shape)))
+        self._join_foreign_pending()
         self._sync_fp8_weights()
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_loss_backward(self.h, _ptr(x0), _ptr(labels), _ptr(eps), seed & 0xFFFFFFFF,
                                                        (seed >> 32) & 0xFFFFFFFF, sample_offset, inv, stage,
                                                        _stream()), "loss_backward")
+
+    def forward_train(self, x: torch.Tensor, noise_level: torch.Tensor) -> torch.Tensor:
+        """model(x, cond) through the TRAINING workspace (activations saved): the forward half of value_and_grad over an
+        arbitrary objective (train_ncsn.py:279-283; include/smd_hip.h smd_engine_forward_train)."""
+        if self.grads is None:
+            raise RuntimeError("forward_train: a training handle (Model.train_engine / create_optimizer) is needed")
+        x = x.to(self.device, torch.float32).contiguous()
+        B = x.shape[0]
+        if tuple(x.shape[1:]) != self.cfg.sample_shape:
+            raise ValueError(f"input shape {tuple(x.shape)} != (B, {self.cfg.sample_shape})")
+        s = noise_level.to(self.device, torch.float32).reshape(-1).contiguous()
+        if s.numel() != B:
+            raise ValueError(f"noise level has {s.numel()} entries for batch {B}")
+        self.bind(B, training=True)
+        self._sync_fp8_weights()
+        self._join_pending()
+        out = torch.empty_like(x)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.smd_engine_forward_train(self.h, _ptr(x), _ptr(s), _ptr(out), _stream()), "forward_train")
+        self._fwd_generation = getattr(self, "_fwd_generation", 0) + 1
+        return out
+
+    def backward_from(self, dpred: torch.Tensor, stage: int = 0) -> None:
+        """Parameter gradients of the last forward_train from d objective / d eps_hat, written to ``self.grads``."""
+        if dpred is not None:
+            dpred = dpred.to(self.device, torch.float32).contiguous()
+            if tuple(dpred.shape) != (self.batch, *self.cfg.sample_shape):
+                raise ValueError(f"dpred shape {tuple(dpred.shape)} != {(self.batch, *self.cfg.sample_shape)}")
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.smd_engine_backward_from(self.h, _ptr(dpred), int(stage), _stream()), "backward_from")
 
     def optimizer_step(self, lr0: float, lr_gamma: float = 0.98, lr_interval: int = 10000, grad_clip: float = 1.0,
                        mu: float = 0.999, grad_scale: float = 1.0, beta1: float = 0.9, beta2: float = 0.999,
@@ -395,11 +440,16 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(self.L.smd_engine_load_state(self.h, _ptr(x), _stream()), "load_state")
 
-    def sample_step(self, io: "_lib.SampleIO") -> None:
+    def sample_step(self, io: "_lib.SampleIO", part: int = 0) -> None:
+        """One reverse iteration; ``part`` 1 / 2: its stem / its output stage + reverse update only (include/smd_hip.h
+        smd_engine_sample_step_part: the pipelined two-chain walk)."""
         self._sync_fp8_weights()
         self._join_pending()
         with torch.cuda.device(self.device):
-            _lib.check(self.L.smd_engine_sample_step(self.h, C.byref(io), _stream()), "sample_step")
+            if part == 0:
+                _lib.check(self.L.smd_engine_sample_step(self.h, C.byref(io), _stream()), "sample_step")
+            else:
+                _lib.check(self.L.smd_engine_sample_step_part(self.h, C.byref(io), int(part), _stream()), "sample_step_part")
 
     @property
     def slot_table(self) -> torch.Tensor:

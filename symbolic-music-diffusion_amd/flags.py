@@ -240,7 +240,7 @@ ENGINE_FLAGS: List[FlagDef] = [
        "checkpoint metadata; inference always uses bf16.", ("bf16", "fp32")),
     _D("dp_algorithm", "enum", "all_reduce", "Data-parallel gradient reduction (more than one rank): one all_reduce per bucket, or "
        "rs_ag = reduce_scatter + all_gather (one direct hop per phase on the 8-GPU xGMI mesh).", ("all_reduce", "rs_ag")),
-    _D("dp_layer_buckets", "bool", True, "Data-parallel: reduce the encoder-stem gradients per layer in backward order, each "
+    _D("dp_layer_buckets", "bool", False, "Data-parallel: reduce the encoder-stem gradients per layer in backward order, each "
        "collective started by the engine's per-layer gradient event instead of at the end of the backward pass."),
     _D("synthetic", "bool", False, "Use synthetic latents clip(0.25*N(0,1),-1,1) instead of --dataset."),
     _D("synthetic_examples", "int", 4096, "Synthetic examples per epoch."),

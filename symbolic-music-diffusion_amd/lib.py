@@ -1,7 +1,7 @@
 """ctypes binding of the C-ABI in include/smd_hip.h.  Fails loudly: there is no CPU fallback.
 
-``get_lib()`` loads ``csrc/libsmd_hip.so`` (building it with hipcc first if it is missing or stale
-and hipcc exists).  Every wrapper raises ``ValueError`` for negative return codes (argument / state
+``get_lib()`` loads ``csrc/libsmd_hip.so`` (building it with hipcc first if it is missing or its embedded build id is
+not the id of this tree's sources -- build.py -- and hipcc exists) and refuses a library of another build id.  Every wrapper raises ``ValueError`` for negative return codes (argument / state
 errors -- the reference raises Python asserts there, e.g. models/ncsn.py:32,40,50,154) and
 ``RuntimeError`` for HIP errors.
 """
@@ -60,6 +60,7 @@ ABI_VERSION = 4          # SMD_ABI_VERSION of include/smd_hip.h this table was w
 _SIGS = {
     "smd_last_error": (C.c_char_p, []),
     "smd_abi_version": (C.c_int, []),
+    "smd_build_id": (C.c_char_p, []),
     "smd_engine_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(c_void)]),
     "smd_engine_destroy": (None, [c_void]),
     "smd_engine_num_tensors": (C.c_int, [c_void]),
@@ -82,6 +83,8 @@ _SIGS = {
     "smd_engine_loss_backward": (C.c_int, [c_void, c_void, c_void, c_void, c_u32, c_u32, c_u32, C.c_float,
                                            C.c_int, c_void]),
     "smd_engine_set_used_alphas": (C.c_int, [c_void, c_void]),
+    "smd_engine_forward_train": (C.c_int, [c_void] * 5),
+    "smd_engine_backward_from": (C.c_int, [c_void, c_void, C.c_int, c_void]),
     "smd_engine_debug_snapshot_bytes": (c_i64, [c_void]),
     "smd_engine_debug_snapshots": (C.c_int, [c_void, c_void, c_i64]),
     "smd_engine_loss_per_sample": (c_void, [c_void]),
@@ -97,6 +100,7 @@ _SIGS = {
     "smd_engine_init_state": (C.c_int, [c_void, c_void, c_u32, c_u32, c_u32, c_void]),
     "smd_engine_load_state": (C.c_int, [c_void, c_void, c_void]),
     "smd_engine_sample_step": (C.c_int, [c_void, C.POINTER(SampleIO), c_void]),
+    "smd_engine_sample_step_part": (C.c_int, [c_void, C.POINTER(SampleIO), C.c_int, c_void]),
     "smd_set_tuning": (C.c_int, [C.c_char_p, C.c_int]),
     "smd_set_timestep": (C.c_int, [c_void, c_i32, c_void]),
     "smd_gemm_bf16_nt": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
@@ -149,6 +153,9 @@ _SIGS = {
     "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_u32,
                                         c_u32, c_u32, c_void, c_void, c_void, c_void]),
     "smd_probe_tr_read": (C.c_int, [c_void, c_void, c_void]),
+    "smd_stream_create_xcd_mask": (C.c_int, [c_u32, C.c_int, C.POINTER(c_void)]),
+    "smd_stream_destroy": (C.c_int, [c_void]),
+    "smd_probe_clock": (C.c_int, [c_void, C.c_int, C.c_int, c_void]),
 }
 
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "smd_hip.h")
@@ -184,8 +191,26 @@ def get_lib() -> C.CDLL:
         fn.argtypes = args
     if lib.smd_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsmd_hip.so ABI {lib.smd_abi_version()} != {ABI_VERSION}; rebuild")
+    have, want = lib.smd_build_id().decode(), _build.source_id()
+    if have != want and os.environ.get("SMD_ALLOW_STALE_LIB") != "1":
+        raise RuntimeError(f"{path} was built from other sources (build id {have}, this tree is {want}) and could not be "
+                           "rebuilt here: run `python -m smd_amd.build` where hipcc exists (SMD_ALLOW_STALE_LIB=1 overrides)")
     _LIB = lib
     return lib
+
+
+_TUNING_EPOCH = 0
+
+
+def set_tuning(key: str, value: int) -> None:
+    """smd_set_tuning (process-wide kernel-selection knob) + a bump of the epoch that cached captured steps are keyed on."""
+    global _TUNING_EPOCH
+    check(get_lib().smd_set_tuning(key.encode(), int(value)), f"set_tuning {key}")
+    _TUNING_EPOCH += 1
+
+
+def tuning_epoch() -> int:
+    return _TUNING_EPOCH
 
 
 def check(rc: int, what: str = "") -> None:

@@ -98,6 +98,15 @@ class Model:
         dev = self.engine.device
         return torch.ops.smd_amd.eps_forward(x.to(dev, torch.float32), cond.to(dev, torch.float32), self._op_id)
 
+    def differentiable(self, ema: bool = False) -> "DifferentiableModel":
+        """``model`` for a generic objective under ``torch.autograd`` (train_ncsn.py:279-283 differentiates ANY callable of the
+        model): the same network on this model's training handle, with the flat parameter buffer as an autograd leaf."""
+        return DifferentiableModel(self, ema)
+
+    def drop_sampler_cache(self) -> None:
+        """Forget the cached sampler graphs and their persistent state / collection / metrics buffers."""
+        self.__dict__.pop("_sampler_graphs", None)
+
     def chain_streams(self, n: int):
         """The streams of the concurrent sampling chains, created ONCE per model: HIP maps streams onto a few hardware queues
         round-robin, and a pair created later in a process can land on one queue, where the two chains serialise (measured:
@@ -131,6 +140,31 @@ class Model:
 
     def num_parameters(self) -> int:
         return self.engine.n_params
+
+
+class DifferentiableModel:
+    """``model(x, cond)`` whose result carries an autograd edge to ``.params`` (a leaf aliasing the engine's flat fp32 parameter
+    buffer): ``objective(batch, dm, ...).backward()`` runs the engine's backward pass from d objective / d eps_hat and leaves
+    the gradient in ``dm.params.grad`` (flat, the layout of ``named_parameters``) and in the training handle's gradient buffer,
+    where ``trainer.train_step`` clips and applies it.  One forward pass may be outstanding per handle."""
+
+    def __init__(self, model: Model, ema: bool = False):
+        from . import ops as _ops
+        self.model = model
+        self.cfg = model.cfg
+        self.engine = model.train_engine(ema)
+        self._op_id = _ops.register_engine(self.engine)
+        self.params = self.engine.params.detach().requires_grad_(True)      # shares storage; its own autograd identity
+
+    def named_parameters(self):
+        return self.engine.named_views()
+
+    def __call__(self, x, cond):
+        x = torch.as_tensor(x)
+        cond = torch.as_tensor(cond)
+        assert x.shape[0] == cond.shape[0], (x.shape, cond.shape)           # models/ncsn.py:32,50
+        dev = self.engine.device
+        return torch.ops.smd_amd.eps_forward_train(x.to(dev, torch.float32), cond.to(dev, torch.float32), self.params, self._op_id)
 
 
 def config_from_kwargs(architecture: str, input_shape: Sequence[int], model_kwargs: dict,
@@ -618,7 +652,9 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     # buffers, the device-resident timestep, Philox key (smd_sample_io.key_ptr) and jax.random key tables are kept with the
     # graphs (one set per model) and refilled per run; the weights are read through the shared operand pack.  A second
     # sample() call then pays no warm-up step, capture or instantiation (7 % of a 1000-step walk).
-    sig = tuple((e.workspace.data_ptr(), e._sched_tensors["film"].data_ptr(), e._sched_tensors["coef"].data_ptr()) for e in engines)
+    # ... and as long as nothing the captured kernels bake in has changed under it: every handle counts its binds, schedule
+    # changes and option changes (Engine.generation); process-wide tuning knobs are part of the key through lib.tuning_epoch()
+    sig = tuple((id(e), e.generation) for e in engines) + (_lib.tuning_epoch(),)
     ckey = (B, nchains, bool(infill), jax_mode, nT, t_hi, len(steps), int(sample_offset), int(n_glob), tuple(init.shape[1:]))
     cache = model.__dict__.setdefault("_sampler_graphs", {})
     entry = cache.get("entry") if graphed else None

@@ -5,6 +5,10 @@ tensors out, launched on torch's current HIP stream; fake-tensor (meta) rules ar
 ``torch.compile`` / ``torch.export`` without running.  There is no CPU implementation: a CPU tensor raises.
 
   smd_amd::eps_forward(x, noise_level, engine)          model(x, cond), models/ncsn.py:141-179 / 125-135
+  smd_amd::eps_forward_train(x, noise_level, params, engine)   the same, DIFFERENTIABLE with respect to the flat parameter
+                                                        buffer: forward in the training workspace, backward =
+                                                        the engine's own backward pass from d/d eps_hat (autograd formula
+                                                        registered with torch.library.register_autograd)
   smd_amd::gemm_bf16_nt(a, bt, bias)                    nn.Dense, bf16 operands, fp32 accumulate -> bf16
   smd_amd::ddpm_reverse_step_(x, eps_hat, coef, t, ...) utils/ebm_utils.py:327-394, in place
   smd_amd::q_sample(x0, alphas_prod_ext, labels, eps)   utils/losses.py:271-296
@@ -52,6 +56,61 @@ def eps_forward(x: torch.Tensor, noise_level: torch.Tensor, engine: int) -> torc
 @eps_forward.register_fake
 def _(x, noise_level, engine):
     return torch.empty_like(x, dtype=torch.float32)
+
+
+# ---- model(x, cond), differentiable w.r.t. the parameters: jax.value_and_grad(loss_fn)(optimizer.target), train_ncsn.py:279-283
+@torch.library.custom_op("smd_amd::eps_forward_train", mutates_args=())
+def eps_forward_train(x: torch.Tensor, noise_level: torch.Tensor, params: torch.Tensor, engine: int) -> torch.Tensor:
+    """``engine`` is a TRAINING handle; ``params`` must be (an alias of) its flat fp32 parameter buffer -- it is an argument so
+    that autograd has an edge to hang the parameter gradient on, the kernels read the engine's own operand pack."""
+    _need_gpu(x, noise_level, params)
+    eng = _ENGINES.get(engine)
+    if eng is None:
+        raise RuntimeError(f"smd_amd::eps_forward_train: no live engine with id {engine} (ops.register_engine)")
+    if params.data_ptr() != eng.params.data_ptr() or params.numel() != eng.params.numel():
+        raise ValueError("smd_amd::eps_forward_train: `params` is not the engine's parameter buffer")
+    return eng.forward_train(x, noise_level)
+
+
+@eps_forward_train.register_fake
+def _(x, noise_level, params, engine):
+    return torch.empty_like(x, dtype=torch.float32)
+
+
+@torch.library.custom_op("smd_amd::eps_backward", mutates_args=())
+def eps_backward(dpred: torch.Tensor, engine: int, generation: int) -> torch.Tensor:
+    """The engine's backward pass from d objective / d eps_hat; returns the flat parameter gradient (a copy of the engine's
+    gradient buffer, which every backward pass overwrites)."""
+    _need_gpu(dpred)
+    eng = _ENGINES.get(engine)
+    if eng is None:
+        raise RuntimeError(f"smd_amd::eps_backward: no live engine with id {engine}")
+    if getattr(eng, "_fwd_generation", 0) != generation:
+        raise RuntimeError("smd_amd::eps_backward: the engine has run another training forward pass since this one (one "
+                           "workspace per handle: call backward() before the next model(x, cond), or use a second handle)")
+    eng.backward_from(dpred)
+    return eng.grads.clone()
+
+
+@eps_backward.register_fake
+def _(dpred, engine, generation):
+    eng = _ENGINES.get(engine)
+    return dpred.new_empty((eng.n_params if eng is not None else 0,), dtype=torch.float32)
+
+
+def _eps_train_setup(ctx, inputs, output):
+    _x, _s, _params, engine = inputs
+    eng = _ENGINES.get(engine)
+    ctx.engine = engine
+    ctx.generation = getattr(eng, "_fwd_generation", 0)
+
+
+def _eps_train_backward(ctx, grad_out):
+    # d/dx is not produced (the reference never differentiates the objective w.r.t. the data either)
+    return None, None, torch.ops.smd_amd.eps_backward(grad_out.contiguous(), ctx.engine, ctx.generation), None
+
+
+torch.library.register_autograd("smd_amd::eps_forward_train", _eps_train_backward, setup_context=_eps_train_setup)
 
 
 @torch.library.custom_op("smd_amd::gemm_bf16_nt", mutates_args=())

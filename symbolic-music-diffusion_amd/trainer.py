@@ -15,7 +15,8 @@ import torch
 
 from .engine import Engine
 from .jax_random import ThreefryKey, diffusion_loss_draws, diffusion_loss_used_alphas
-from .ncsn import Model, PRNGKey, _dsm_draws, _ensure_any_schedule, _ensure_schedule, diffusion_loss
+from .ncsn import (Model, PRNGKey, _dsm_draws, _ensure_any_schedule, _ensure_schedule, denoising_score_matching_loss,
+                   diffusion_loss)
 
 
 @dataclass
@@ -74,14 +75,19 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     (+ EMA, fused).  ``learning_rate`` is the step's LR as in the reference; pass ``lr_gamma`` /
     ``lr_interval`` instead to let the kernel evaluate the stepped schedule from its own step
     counter (learning_rate is then lr0).  ``continuous_noise`` is FLAGS.continuous_noise (:278): False draws the labels
-    in [0, T) and gives label 0 its real uniform noise level (utils/losses.py:272-286).  Returns (optimizer, metrics{'loss','grad','lr'})."""
-    name = getattr(objective, "__name__", "")
-    if name not in ("diffusion_loss", "denoising_score_matching_loss"):
-        raise ValueError("the HIP engine implements the 'ddpm' (diffusion_loss) and 'dsm' "
-                         "(denoising_score_matching_loss) objectives; 'ssm' needs a double backward")
+    in [0, T) and gives label 0 its real uniform noise level (utils/losses.py:272-286).  Returns (optimizer, metrics{'loss','grad','lr'}).
+
+    ``objective``: ``diffusion_loss`` / ``denoising_score_matching_loss`` of this package run fused (q-sample, forward, loss and
+    backward as one engine call).  ANY other callable ``objective(batch, model, sigmas, rng, continuous_noise, 'mean')`` written in
+    torch is differentiated as the reference differentiates it (jax.value_and_grad, :279-283): ``model`` is then a
+    ``DifferentiableModel`` whose ``model(x, cond)`` runs the engine's forward and whose autograd backward is the engine's backward
+    pass from d objective / d eps_hat (one model call per objective; second-order objectives like 'ssm' are not supported)."""
     eng = optimizer.engine
     batch = torch.as_tensor(batch).to(eng.device, torch.float32).contiguous()
-    dsm = name == "denoising_score_matching_loss"
+    if objective is not diffusion_loss and objective is not denoising_score_matching_loss:
+        return _train_step_generic(objective, batch, optimizer, sigmas, rng, learning_rate, grad_clip=grad_clip, mu=mu, comm=comm,
+                                   lr_gamma=lr_gamma, lr_interval=lr_interval, continuous_noise=continuous_noise)
+    dsm = objective is denoising_score_matching_loss
     if dsm:
         _ensure_any_schedule(eng)
     else:
@@ -145,6 +151,36 @@ def train_step(objective, batch, optimizer: Optimizer, sigmas, rng: PRNGKey, lea
     return optimizer, metrics
 
 
+def _train_step_generic(objective, batch, optimizer: Optimizer, sigmas, rng, learning_rate, *, grad_clip, mu, comm, lr_gamma,
+                        lr_interval, continuous_noise):
+    """train_ncsn.py:279-287 for an arbitrary objective: torch autograd over ``objective`` with the engine's forward / backward
+    underneath (ops.py smd_amd::eps_forward_train), then the same fused clip + Adam (+ EMA) sweep as the fused objectives."""
+    eng = optimizer.engine
+    dm = getattr(optimizer, "_differentiable", None)
+    if dm is None:
+        dm = optimizer._differentiable = optimizer.target.differentiable(ema=eng.ema is not None)
+    eng.set_opt_overlap(0)
+    dm.params.grad = None
+    with torch.enable_grad():
+        loss = objective(batch, dm, sigmas, rng, continuous_noise, "mean")
+    if not (torch.is_tensor(loss) and loss.requires_grad and loss.numel() == 1):
+        raise ValueError("train_step: objective(batch, model, sigmas, rng, continuous_noise, 'mean') must return a scalar tensor "
+                         "computed from model(x, cond)")
+    loss.backward()
+    if dm.params.grad is None:
+        raise ValueError("train_step: the objective did not reach the model's parameters")
+    # the engine's gradient buffer holds the last backward pass; autograd's accumulated leaf gradient is the authoritative one
+    eng.grads.copy_(dm.params.grad)
+    dm.params.grad = None
+    world = 1
+    if comm is not None:
+        world = comm.world_size
+        comm.reduce_async(eng.grads)
+        comm.wait()
+    eng.optimizer_step(learning_rate, lr_gamma, lr_interval, grad_clip, mu, 1.0 / world)     # the objective's mean is per rank
+    return optimizer, LazyMetrics(loss=loss.detach(), grad=eng.metrics[1], lr=eng.metrics[2])
+
+
 def eval_step(objective, batch, model: Model, sigmas, rng: PRNGKey, continuous_noise: bool = True):
     """train_ncsn.py:206-221: summed loss of one batch."""
     return objective(batch, model, sigmas, rng, continuous_noise, "sum")
@@ -175,10 +211,17 @@ class GradComm:
     link to every other, so each of the two phases is ONE hop of n/8 per peer over 7 links in parallel
     where a ring makes 2 x 7 dependent hops; which one RCCL's own all_reduce picks is its tuning, this makes it a choice.
     ``layer_buckets``: the stem slice is reduced per encoder layer in backward order, each collective gated by the engine's
-    per-layer gradient event (train_step; engine option dp_layer_events) instead of by the end of the stem backward."""
+    per-layer gradient event (train_step; engine option dp_layer_events) instead of by the end of the stem backward.  OFF by
+    default: six extra 2.4 MB collectives per step are latency-bound on a real communicator (a launch + >= 20 us each on a
+    stream that competes with the stem backward for CUs) and have not been measured to win on RCCL.
+    ``measure_exposed``: HIP events around the point where the compute stream waits for the communication stream;
+    ``exposed_comm_us()`` returns the mean stall per step (what the overlap did NOT hide).
+    ``emulate_load`` (dry runs on one GPU over gloo): every reduction first runs a copy + add of the chunk's size on the
+    communication stream -- kernels of a collective's shape sharing the CUs with the backward pass, which gloo's host-side
+    reduction would not provide."""
 
     def __init__(self, group=None, buckets: int = 1, payload: str = "fp32", algorithm: str = "all_reduce",
-                 layer_buckets: bool = True):
+                 layer_buckets: bool = False, measure_exposed: bool = False, emulate_load: bool = False):
         import torch.distributed as dist
         if payload not in ("fp32", "bf16"):
             raise ValueError(f"payload must be 'fp32' or 'bf16', got {payload!r}")
@@ -192,6 +235,11 @@ class GradComm:
         self.payload = payload
         self.algorithm = algorithm
         self.layer_buckets = bool(layer_buckets)
+        self.measure_exposed = bool(measure_exposed)
+        self.emulate_load = bool(emulate_load)
+        self.collectives = 0                # issued since construction (the bench line reports collectives per step)
+        self._exposed = []                  # (event before the stall, event after it) per wait()
+        self._load = {}                     # numel -> two scratch buffers of the emulated collective
         self._works = []
         self._stream = None
         self._stage = {}                    # (data_ptr, numel) -> bf16 staging buffer
@@ -207,6 +255,13 @@ class GradComm:
     def _collective(self, buf: torch.Tensor) -> None:
         """SUM over the ranks of ``buf`` in place, asynchronously (the works are collected in self._works)."""
         d, W = self.dist, self.world_size
+        self.collectives += 1
+        if self.emulate_load and buf.is_cuda:
+            sc = self._load.get(buf.numel())
+            if sc is None:
+                sc = self._load[buf.numel()] = (torch.empty_like(buf), torch.ones_like(buf))
+            sc[0].copy_(buf)                # the receive copy ...
+            sc[0].add_(sc[1])               # ... and the reduction of a ring step, on the communication stream
         if self.algorithm == "all_reduce" or buf.numel() < 2 * W:
             self._works.append(d.all_reduce(buf, op=d.ReduceOp.SUM, group=self.group, async_op=True))
             return
@@ -266,7 +321,39 @@ class GradComm:
         self._works.clear()
         self._pending.clear()
         if cuda:
-            torch.cuda.current_stream().wait_stream(self._stream)
+            cur = torch.cuda.current_stream()
+            if self.measure_exposed:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+            cur.wait_stream(self._stream)
+            if self.measure_exposed:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(cur)
+                self._exposed.append((e0, e1))
+
+    def exposed_comm_us(self) -> Optional[float]:
+        """Mean time per step the compute stream stood waiting for the communication stream since the last call (needs
+        ``measure_exposed``); blocks until the recorded events have completed."""
+        if not self._exposed:
+            return None
+        self._exposed[-1][1].synchronize()
+        v = sum(a.elapsed_time(b) for a, b in self._exposed) * 1e3 / len(self._exposed)
+        self._exposed.clear()
+        return v
+
+    def describe(self) -> Dict[str, object]:
+        """What ran: backend, library version, world size and the shape of the exchange (for the bench line)."""
+        d = self.dist
+        backend = d.get_backend(self.group)
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = "unknown"
+        return {"backend": backend, "library": "RCCL" if backend == "nccl" else backend, "version": ver,
+                "world_size": self.world_size, "algorithm": self.algorithm, "buckets_per_stage": self.buckets,
+                "payload": self.payload, "layer_buckets": self.layer_buckets, "emulated_load": self.emulate_load}
 
     def broadcast_params(self, flat: torch.Tensor, src: int = 0) -> None:
         if self.world_size > 1:

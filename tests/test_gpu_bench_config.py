@@ -358,3 +358,30 @@ def test_bench_script_with_two_ranks_on_one_gpu():
     assert "TEST RUN" in d["data"]
     assert d["value"] > 0 and np.isfinite(d["final_loss"]) and 0.5 < d["final_loss"] < 3.0
     assert d["extra_configs"] is None and d["cpu_baseline"] is None          # single-GPU extras stay out of a multi-rank line
+    # the line proves what ran between the ranks: library, world size, shape of the exchange, measured exposed communication
+    dp = d["config"]["dp"]
+    assert dp["backend"] == "gloo" and dp["world_size"] == 2 and dp["algorithm"] == "all_reduce" and dp["layer_buckets"] is False
+    assert dp["collectives_per_step"] == 2.0                                 # output-stage slice + stem slice, nothing else
+    assert dp["exposed_comm_us"] is not None and dp["exposed_comm_us"] >= 0
+
+
+def test_bench_dp_dry_run_on_one_gpu():
+    """`bench.py --dp-dry-run`: the multi-GPU train step on CUDA gradient tensors with a communication stream that runs kernels of a
+    collective's shape beside the backward pass (two ranks on cuda:0 over gloo).  The reduced gradient and the parameters after 3
+    steps must be bitwise the same with that load, with it again, and without it, and equal on both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SMD_BENCH_SHARE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dp-dry-run", "--steps", "3", "--warmup", "1", "--dp-layer-buckets", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])["dp_dry_run"]
+    assert d["ok"] and d["ranks_agree"] and all(d["bitwise"].values()), d
+    assert d["comm"]["emulated_load"] in (True, False) and d["comm"]["layer_buckets"] is True and d["world"] == 2

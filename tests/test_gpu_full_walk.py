@@ -1,0 +1,200 @@
+"""Parity holes VERDICT r4 named that need no JAX:
+
+(a) a FULL-LENGTH free-running reverse walk (utils/ebm_utils.py:399-401: 1000 iterations of sample_with_beta, :327-394) with
+    explicit per-step noise against the fp64 oracle: final state, all 39 written collection slots, the never-written slot 1, and
+    the (4, 1000, 1) metrics -- the existing tests compare <= 50-step rollouts only;
+(b) parity on TRAINED weights: a few hundred engine train steps move the LayerNorm / FiLM statistics away from the
+    random-init ones every other parity test uses (outlier features, grown FiLM scales: what bf16 trunk storage and the e4m3
+    row scales are sensitive to); the trained parameters are exported through named_views and forward / loss / gradient /
+    three reverse steps are compared again at B = 256, in bf16 and fp8 (utils/losses.py:250-308, train_ncsn.py:260-288).
+
+Tolerances: SURVEY section 8(c).  A free-running walk has no per-step bound there (the bf16 eps_hat error of each step is fed
+back into the state); the bound asserted here is the measured divergence with head-room, printed per snapshot.
+"""
+import numpy as np
+import pytest
+import torch
+
+import ddpm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+BETAS = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make(C, L, H, K, seed=0, dtype="bf16"):
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    ocfg = O.NetConfig(data_channels=C, num_layers=L, num_heads=H, num_mlp_layers=K)
+    p = O.init_params(ocfg, seed, torch.float64)
+    g = torch.Generator().manual_seed(seed + 1)
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = 0.1 * torch.randn(p[k].shape, generator=g, dtype=torch.float64)
+        elif k.endswith(".scale"):
+            p[k] = 1 + 0.1 * torch.randn(p[k].shape, generator=g, dtype=torch.float64)
+    cfg = NetConfig(architecture="TransformerDDPM", data_channels=C, seq_len=32, num_layers=L, num_heads=H,
+                    num_mlp_layers=K, num_timesteps=1000, dtype=dtype)
+    model = N.Model(cfg, "cuda:0", seed=None)
+    model.engine.load_named(p)
+    return ocfg, p, model
+
+
+def step_noise(B, C, t):
+    g = torch.Generator().manual_seed(100_000 + t)
+    return torch.randn(B, 32, C, generator=g)
+
+
+@pytest.mark.parametrize("name,C,L,H,K,B,tol_state,tol_metric", [
+    ("small", 42, 2, 8, 1, 4, 1.5e-2, 2e-3),        # measured (profiles/r5b_full_walk_tests.txt): 5.6e-3 / 2.1e-4
+    ("base", 512, 6, 8, 2, 2, 1.5e-2, 2e-3),        # measured: 6.6e-3 / 1.2e-4
+])
+def test_full_T_walk_against_the_fp64_oracle(name, C, L, H, K, B, tol_state, tol_metric):
+    import smd_amd.ncsn as N
+    ocfg, p, model = make(C, L, H, K)
+    g = torch.Generator().manual_seed(2718)
+    init = torch.randn(B, 32, C, generator=g)
+    with torch.no_grad():
+        ref_x, ref_c, ref_m = O.diffusion_dynamics(O.make_model(p, ocfg), BETAS, init.double(),
+                                                   lambda t: step_noise(B, C, t).double())
+    x, coll, met = N.diffusion_dynamics(N.PRNGKey(0), model, BETAS, init, noises=lambda t: step_noise(B, C, t))
+    torch.cuda.synchronize()
+    assert tuple(coll.shape) == (41, B, 32, C) and tuple(met.shape) == (4, 1000, 1)
+    # bookkeeping (utils/ebm_utils.py:322-325,387-394): slot 0 = start, slot 1 never written, 39 snapshots, final state absent
+    assert torch.equal(coll[0].cpu(), init)
+    assert float(coll[1].abs().max()) == 0.0 and float(ref_c[1].abs().max()) == 0.0
+    table = O.collection_index_table(1000)
+    slot_t = {O.collection_slot_for_t(1000, t, table): t for t in range(1000) if O.collection_slot_for_t(1000, t, table) >= 0}
+    assert sorted(slot_t) == list(range(2, 41)) and slot_t[40] == 1 and slot_t[2] == 975
+    per_slot = []
+    for k in range(2, 41):
+        assert float(coll[k].abs().max()) > 0
+        per_slot.append(rel(coll[k], ref_c[k]))
+    e_final = rel(x, ref_x)
+    print(f"[{name}] free-running T = 1000 walk, B = {B}: final state rel {e_final:.3e}; snapshot rel by t: "
+          + " ".join(f"{slot_t[k]}:{per_slot[k - 2]:.1e}" for k in (2, 8, 14, 20, 27, 33, 39, 40)) + f"; worst {max(per_slot):.3e}")
+    assert e_final < tol_state and max(per_slot) < tol_state
+    assert float(x.abs().max()) <= 1.0 + 1e-6                      # the t = 0 step returns the clipped x0
+    # metrics rows (grad_norm, step_norm, alpha_prod, noise_norm) for every one of the T iterations
+    m, r = met.cpu().double(), ref_m.double()
+    e_rows = [rel(m[i], r[i]) for i in range(4)]
+    worst_t = float(((m[0, :, 0] - r[0, :, 0]).abs() / r[0, :, 0].abs()).max())
+    print(f"[{name}] metrics rel: slope {e_rows[0]:.2e} step {e_rows[1]:.2e} alpha {e_rows[2]:.2e} noise {e_rows[3]:.2e}; "
+          f"worst single-t slope error {worst_t:.2e}")
+    assert e_rows[2] < 1e-6 and e_rows[3] < 1e-5                   # table data / norms of the explicit draws: fp32 exact-ish
+    assert e_rows[0] < tol_metric and e_rows[1] < tol_metric
+    assert float(r[3, -1, 0]) == pytest.approx(1e-5, rel=1e-3) and float(m[3, -1, 0]) == pytest.approx(1e-5, rel=1e-3)   # t = 0: z = 0
+
+
+def test_full_T_walk_graph_replay_equals_eager_bitwise():
+    """The captured-graph walk IS the eager walk for all 1000 iterations (one chain; Philox draws keyed by (rng, sample, t))."""
+    import smd_amd.ncsn as N
+    _, _, model = make(42, 2, 8, 1)
+    init = torch.randn(4, 32, 42, generator=torch.Generator().manual_seed(5))
+    a = N.diffusion_dynamics(N.PRNGKey(9), model, BETAS, init, use_graph=True)
+    b = N.diffusion_dynamics(N.PRNGKey(9), model, BETAS, init, use_graph=False)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    assert float(a[1][1].abs().max()) == 0 and all(float(a[1][k].abs().max()) > 0 for k in range(2, 41))
+
+
+# ------------------------------------------------------------------ (b) trained weights
+def _train(model, steps, B=256, C=512, lr=1e-3):
+    """`steps` engine train steps (configs/ddpm-base.cfg: Adam, lr 1e-3, grad_clip 1) on structured synthetic latents -- a
+    low-rank pattern + noise drawn on the device, so the net has something to fit and its FiLM / LayerNorm statistics move --
+    with the engine's own Philox label / eps draws."""
+    import smd_amd.ncsn as N
+    from smd_amd.trainer import create_optimizer, train_step
+    g = torch.Generator(device="cuda").manual_seed(99)
+    basis = torch.randn(8, 32, C, generator=g, device="cuda")
+
+    def batch():
+        coef = torch.randn(B, 8, generator=g, device="cuda")
+        return torch.clamp(0.35 * torch.einsum("bk,ksc->bsc", coef, basis) / 8 ** 0.5
+                           + 0.05 * torch.randn(B, 32, C, generator=g, device="cuda"), -1, 1)
+
+    opt = create_optimizer(model, lr, ema=False)
+    losses = []
+    for it in range(steps):
+        x0 = batch()
+        _, m = train_step(N.diffusion_loss, x0, opt, BETAS, N.PRNGKey(it), lr, grad_clip=1.0)
+        if it % 100 == 0 or it == steps - 1:
+            losses.append(float(m["loss"]))
+    torch.cuda.synchronize()
+    return opt, losses, x0.cpu()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_parity_on_trained_weights(dtype):
+    import smd_amd.lib as lib
+    import smd_amd.ncsn as N
+    B, C = 256, 512
+    ocfg, p0, model = make(C, 6, 8, 2, dtype=dtype)
+    opt, losses, x_last = _train(model, 1500)
+    print(f"[trained {dtype}] loss every 100 of the 1500 steps: " + " ".join(f"{v:.3f}" for v in losses))
+    assert losses[-1] < 0.9, "training did not get below the predict-zero plateau (loss 1.0)"
+    eng = opt.engine
+    p = {k: v.detach().float().cpu().clone() for k, v in model.engine.named_views().items()}     # fp32 oracle at B = 256
+    drift = {k: float((p[k].double() - p0[k]).norm() / (p0[k].norm() + 1e-12)) for k in p}
+    film = [k for k in p if k.startswith("film") and k.endswith("scale.kernel")]
+    print(f"[trained {dtype}] parameter drift: median {np.median(list(drift.values())):.3f}, FiLM scale kernels "
+          + " ".join(f"{drift[k]:.3f}" for k in film))
+    g = torch.Generator().manual_seed(31)
+    x0 = x_last
+    labels = torch.randint(1, 1001, (B,), generator=g)
+    eps = torch.randn(B, 32, C, generator=g)
+    # ---- forward + loss + gradient on the trained parameters
+    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    base_model = O.make_model(leaf, ocfg)
+    seen = {}
+
+    def capturing(x, cond):
+        out = base_model(x, cond)
+        seen["pred"] = out.detach()
+        return out
+
+    loss_ref = O.diffusion_loss(x0, capturing, BETAS, labels.numpy(), eps, "none")
+    loss_ref.mean().backward()
+    eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
+    torch.cuda.synchronize()
+    tol_fwd = 1e-2 if dtype == "bf16" else 5e-2
+    e_pred = rel(eng.last_pred(), seen["pred"])
+    m_eng, m_ref = float(eng.loss_per_sample().mean()), float(loss_ref.mean())
+    gv = eng.named_views(eng.grads)
+    num = sum(float((gv[k].double().cpu() - leaf[k].grad.double()).pow(2).sum()) for k in leaf)
+    den = sum(float(leaf[k].grad.double().pow(2).sum()) for k in leaf)
+    e_grad = (num / den) ** 0.5
+    # how hard the trained activations are: outlier ratio (max |x| / rms) of the 2048-wide trunk entering the output LayerNorm
+    yK = eng.debug_tensor("y", ocfg.num_mlp_layers).float()
+    print(f"[trained {dtype}] trunk before the output LayerNorm: rms {float(yK.pow(2).mean().sqrt()):.3f}, max |x| / rms "
+          f"{float(yK.abs().max() / yK.pow(2).mean().sqrt()):.1f}; |eps_hat| rms {float(seen['pred'].pow(2).mean().sqrt()):.3f}")
+    print(f"[trained {dtype}] eps_hat rel {e_pred:.3e}; loss {m_eng:.6f} vs {m_ref:.6f} ({abs(m_eng - m_ref) / m_ref:.2e}); "
+          f"gradient whole-vector rel {e_grad:.3e}")
+    assert e_pred < tol_fwd
+    assert abs(m_eng - m_ref) / m_ref < (5e-3 if dtype == "bf16" else 2.5e-2)
+    assert e_grad < (1e-2 if dtype == "bf16" else 5e-2)
+    # ---- three reverse steps with explicit draws (utils/ebm_utils.py:327-394) on the trained parameters
+    init = torch.randn(B, 32, C, generator=g)
+    zs = {t: torch.randn(B, 32, C, generator=g) for t in (999, 998, 997)}
+    with torch.no_grad():
+        ref, _, mref = O.diffusion_dynamics(O.make_model(p, ocfg), BETAS, init, lambda t: zs[t], t_stop=997)
+    got, _, mgot = N.diffusion_dynamics(N.PRNGKey(0), model, BETAS, init, noises=lambda t: zs[t], t_stop=997)
+    e_state = rel(got, ref)
+    e_slope = rel(mgot[0, :3], mref[0, :3])
+    print(f"[trained {dtype}] 3 reverse steps: state rel {e_state:.3e}; slope metric rel {e_slope:.3e}")
+    assert e_state < 1e-2
+    assert e_slope < tol_fwd
+    # ---- and a late, low-noise step where the x0 prediction matters (t = 20 .. 18), teacher-forced from a mid-walk state
+    xs = torch.clamp(x0 + 0.05 * torch.randn(B, 32, C, generator=g), -1.5, 1.5)
+    z2 = {t: torch.randn(B, 32, C, generator=g) for t in (20, 19, 18)}
+    with torch.no_grad():
+        ref2, _, _ = O.diffusion_dynamics(O.make_model(p, ocfg), BETAS, xs, lambda t: z2[t], t_start=20, t_stop=18)
+    got2, _, _ = N.diffusion_dynamics(N.PRNGKey(0), model, BETAS, xs, noises=lambda t: z2[t], t_start=20, t_stop=18)
+    e2 = rel(got2, ref2)
+    print(f"[trained {dtype}] reverse steps t = 20..18: state rel {e2:.3e}")
+    assert e2 < 1e-2
