@@ -81,6 +81,9 @@ def parse(argv=None):
                          "reduced gradients are bitwise the same with and without that load and on both ranks")
     ap.add_argument("--sampler-chains", type=int, default=2, choices=[1, 2],
                     help="graph-replayed sampling as two concurrent half-batch chains (default) or one chain")
+    ap.add_argument("--sampler-unroll", type=int, default=-1,
+                    help="two chains: reverse steps per captured graph of the pipelined walk (-1: the largest of 8, 4, 2, 1 that divides "
+                         "--steps, capped by smd_amd's own default; 0: two free-running one-step graphs, the round-4 arrangement)")
     ap.add_argument("--no-roofline-microbench", action="store_true",
                     help="skip the back-to-back launches of the dominant kernel (profiling runs: the trace then holds the timed loops only)")
     return ap.parse_args(argv)
@@ -281,6 +284,15 @@ class Workload:
             ch["io"] = io
             self.chains.append(ch)
         self.walked = 0
+        # the pipelined two-chain walk of ncsn.diffusion_dynamics: chain 0 = (output stage, next stem) x U per graph, chain 1 =
+        # (stem, output stage) x U, every replay waiting for the other chain's previous replay; U must divide the block length
+        self.unroll = 0
+        if nchains == 2:
+            want = N._sampler_pipeline_unroll() if a.sampler_unroll < 0 else a.sampler_unroll
+            if want > 0:
+                self.unroll = max(u for u in (8, 4, 2, 1) if u <= want and a.steps % u == 0)
+        self._ev = [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]
+        self._replays = 0
 
     # ---- the two halves of a step
     def one_train(self):
@@ -300,19 +312,38 @@ class Workload:
                 ch["eng"].init_state(ch["x"], 4321 + self.restarts, self.rank * self.B + c * hB)
             lib.check(lib.get_lib().smd_set_timestep(ch["t_ptr"].data_ptr(), 999, st.cuda_stream))
         self.walked = 0
+        if self.unroll and self.chains[0]["graph"] is not None:       # the pipeline's prologue: chain 0's first stem
+            ch = self.chains[0]
+            with torch.cuda.stream(ch["stream"]):
+                ch["eng"].sample_step(ch["io"], 1)
+            self._replays = 0
+
+    def sample_steps(self, n: int):
+        """exactly `n` reverse steps of every chain (n a multiple of the graphs' unroll once they are captured)"""
+        torch = self.torch
+        per = self.unroll if (self.unroll and self.chains[0]["graph"] is not None) else 1
+        assert n % per == 0, (n, per)
+        for _ in range(n // per):
+            # a reverse walk has T = 1000 iterations: start over before t would pass 0 (the kernels also refuse t < 0)
+            if self.walked + per > 990:
+                self._reset_t()
+            self.walked += per
+            for c, ch in enumerate(self.chains):
+                if ch["stream"] is None:
+                    self._run_chain(ch)
+                    continue
+                with torch.cuda.stream(ch["stream"]):
+                    if per == self.unroll and self.unroll:
+                        if self._replays > 0:
+                            ch["stream"].wait_event(self._ev[1 - c][(self._replays - 1) & 1])
+                        ch["graph"].replay()
+                        self._ev[c][self._replays & 1].record(ch["stream"])
+                    else:
+                        self._run_chain(ch)
+            self._replays += 1
 
     def one_sample(self):
-        torch = self.torch
-        # a reverse walk has T = 1000 iterations: start over before t would pass 0 (the kernels also refuse t < 0)
-        if self.walked >= 990:
-            self._reset_t()
-        self.walked += 1
-        for ch in self.chains:
-            if ch["stream"] is not None:
-                with torch.cuda.stream(ch["stream"]):
-                    self._run_chain(ch)
-            else:
-                self._run_chain(ch)
+        self.sample_steps(1)
 
     @staticmethod
     def _run_chain(ch):
@@ -332,7 +363,8 @@ class Workload:
             # weights change under training: tables/operand pack are refreshed per sampling run in the real
             # sampler; here the step content is what is timed, so one captured step per chain is replayed.
             torch.cuda.synchronize()
-            for ch in self.chains:
+            U = self.unroll
+            for c, ch in enumerate(self.chains):
                 s = ch["stream"] if ch["stream"] is not None else torch.cuda.Stream(device=self.dev)
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s):
@@ -340,9 +372,16 @@ class Workload:
                 s.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s):
-                    ch["eng"].sample_step(ch["io"])
+                    if U:
+                        for _ in range(U):
+                            for part in ((2, 1) if c == 0 else (1, 2)):
+                                ch["eng"].sample_step(ch["io"], part)
+                    else:
+                        ch["eng"].sample_step(ch["io"])
                 ch["graph"] = g
-            self.one_sample()
+            torch.cuda.synchronize()
+            self._reset_t()
+            self.sample_steps(max(U, 1))
         torch.cuda.synchronize()
         self._reset_t()
         torch.cuda.synchronize()
@@ -357,8 +396,7 @@ class Workload:
         barrier()
         t1 = time.perf_counter()
         if do_sample:
-            for _ in range(steps):
-                self.one_sample()
+            self.sample_steps(steps)
         barrier()
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
@@ -570,6 +608,9 @@ def main():
         ex = comm.exposed_comm_us()
         dp_stats = {"collectives_per_step": round((comm.collectives - c0) / n_train, 2),
                     "exposed_comm_us": None if ex is None else round(ex, 1)}
+    sample_desc = (f"hipGraph replay, 2 half-batch chains pipelined (chain A: output stage + next stem, chain B: stem + output stage; "
+                   f"{w.unroll} steps per graph, cross-chain event per replay)" if w.unroll
+                   else "hipGraph replay, 2 free-running half-batch chains")
     fwd = FLOP_FWD_PER_SEQ[a.config] * a.batch
     head = summarise(blocks, a.steps, world, do_train, do_sample, fwd)
     loss = w.final_loss() if do_train else float("nan")
@@ -637,7 +678,7 @@ def main():
                                   "exposed_comm_us": dp_stats.get("exposed_comm_us"),
                                   "what": "exposed_comm_us = mean stall of the compute stream at GradComm.wait() per train step (HIP events)"}}
                           if world > 1 else {}),
-                       "sample_step": "eager" if a.no_graph else ("hipGraph replay, 2 concurrent half-batch chains" if nch == 2 else "hipGraph replay"),
+                       "sample_step": "eager" if a.no_graph else (sample_desc if nch == 2 else "hipGraph replay"),
                        "rng": a.rng_impl},
             "repeats": a.repeats, "block_values": head["block_values"], "spread": head["spread"],
             "reported_block": "median of the blocks by total time; each block = exactly `steps` train steps + `steps` reverse steps",

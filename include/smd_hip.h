@@ -428,6 +428,8 @@ int smd_stream_destroy(void* stream);
 /* lab probe: `blocks` one-wave workgroups spin for ~spin_us; out[8 * b + ..] = XCC id, HW_ID, shader-clock ticks (2 words),
  * 100 MHz ticks (2 words), start time in 100 MHz ticks (2 words) -- where a stream runs and at which clock */
 int smd_probe_clock(uint32_t* out, int blocks, int spin_us, void* stream);
+/* lab probe: every XCD reads all `bytes` of `p`, leaving it resident in all eight L2s (sink: one writable dword or NULL) */
+int smd_probe_l2_warm(const void* p, int64_t bytes, uint32_t* sink, void* stream);
 /* lane-level probe of ds_read_b64_tr_b16 (debug): out[64][4] = values read from a 2 KiB linear image */
 int smd_probe_tr_read(const smd_bf16* image_1024, smd_bf16* out_256, void* stream);
 

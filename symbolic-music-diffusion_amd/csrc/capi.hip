@@ -473,6 +473,25 @@ __global__ __launch_bounds__(64) void probe_clock_kernel(uint32_t* __restrict__ 
     o[6] = (uint32_t)r0; o[7] = (uint32_t)(r0 >> 32);
   }
 }
+// lab probe: every XCD reads all `bytes` of `p` (workgroup b runs on XCD b % 8 and reads slice b / 8): the buffer is then
+// resident in all eight L2s -- what a weight prefetch ahead of a latency-bound kernel would achieve
+__global__ __launch_bounds__(256) void l2_warm_kernel(const uint4* __restrict__ p, size_t n16, int slices, uint32_t* __restrict__ sink) {
+  const int slice = blockIdx.x >> 3;
+  const size_t per = (n16 + slices - 1) / slices;
+  const size_t lo = (size_t)slice * per, hi = lo + per < n16 ? lo + per : n16;
+  uint32_t acc = 0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += 256) { const uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+  if (acc == 0x9E3779B9u && sink) *sink = acc;     // never true in practice: keeps the loads
+}
+int smd_probe_l2_warm(const void* p, int64_t bytes, uint32_t* sink, void* stream) {
+  SMD_ARG_CHECK(p && bytes >= 16 && bytes % 16 == 0, "smd_probe_l2_warm: bad argument");
+  const size_t n16 = (size_t)bytes / 16;
+  int slices = (int)((n16 + 2047) / 2048);          // <= 32 KiB per workgroup
+  if (slices > 256) slices = 256;
+  hipLaunchKernelGGL(l2_warm_kernel, dim3(8 * slices), dim3(256), 0, S(stream), reinterpret_cast<const uint4*>(p), n16, slices, sink);
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
 int smd_probe_clock(uint32_t* out, int blocks, int spin_us, void* stream) {
   SMD_ARG_CHECK(out && blocks > 0 && spin_us >= 0, "smd_probe_clock: bad argument");
   hipLaunchKernelGGL(probe_clock_kernel, dim3(blocks), dim3(64), 0, S(stream), out, spin_us);

@@ -156,6 +156,7 @@ _SIGS = {
     "smd_stream_create_xcd_mask": (C.c_int, [c_u32, C.c_int, C.POINTER(c_void)]),
     "smd_stream_destroy": (C.c_int, [c_void]),
     "smd_probe_clock": (C.c_int, [c_void, C.c_int, C.c_int, c_void]),
+    "smd_probe_l2_warm": (C.c_int, [c_void, c_i64, c_void, c_void]),
 }
 
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "smd_hip.h")

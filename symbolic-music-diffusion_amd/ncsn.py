@@ -592,6 +592,14 @@ def _sampler_chains(model: "Model", B: int, graphed: bool) -> int:
     return 2 if (B % 2 == 0 and B >= 128 and rows % 256 == 0 and eng.cfg.mlp_dims % 256 == 0) else 1
 
 
+def _sampler_pipeline_unroll() -> int:
+    """Iterations per captured graph of the pipelined two-chain walk (0: the two chains free-running as one-step graphs, the
+    round-4 arrangement; SMD_SAMPLER_PIPELINE=0 / SMD_SAMPLER_UNROLL=U in the environment)."""
+    if os.environ.get("SMD_SAMPLER_PIPELINE", "1") == "0":
+        return 0
+    return max(1, int(os.environ.get("SMD_SAMPLER_UNROLL", "4")))
+
+
 def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=None, denoise=None, infill=False,
                        infill_samples=None, infill_masks=None, *, noises: Optional[Callable] = None,
                        infill_noises: Optional[Callable] = None, t_start: Optional[int] = None, t_stop: int = 0,
@@ -639,10 +647,16 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
         ik_d = torch.from_numpy(ik.view(np.int32).copy()).to(dev) if infill else None
 
     # Two concurrent half-batch chains (graph replay only): samples are independent, so the batch is walked as two chains
-    # of B/2 on two streams, each a replayed graph of its own engine handle; one chain's launch-latency-bound encoder
-    # kernels and GEMM epilogues then overlap the other's MFMA phases (-5 % per step at B = 256, profiles/README.md).
-    # Draws are keyed by the GLOBAL sample index, so the result does not depend on the split.
+    # of B/2 on two streams, each its own engine handle; one chain's launch-latency-bound encoder kernels then overlap the
+    # other's MFMA phases.  Draws are keyed by the GLOBAL sample index, so the result does not depend on the split.
+    # PIPELINED (default): two FREE-running chains drift into phase within ~100 iterations -- both in their encoder, then both
+    # in their 2048-wide GEMMs -- which is the slow mode (1650-1740 steps/s against 1900-2000 half a period apart: the
+    # round-4 "bimodality", profiles/r5a_chain_phase_*.txt).  So chain A is captured as (output stage + reverse update of
+    # iteration k, stem of iteration k + 1) and chain B as (stem, output stage) of iteration k, `unroll` iterations per graph,
+    # and every replay of one chain waits for the previous replay of the other: the phase is re-locked every `unroll`
+    # iterations and the two halves always complement each other (include/smd_hip.h smd_engine_sample_step_part).
     nchains = _sampler_chains(model, B, graphed)
+    unroll = _sampler_pipeline_unroll() if nchains == 2 else 0
     engines = model.chain_engines(nchains) if nchains > 1 else [eng]
     h = B // nchains
     for c, e in enumerate(engines):
@@ -655,7 +669,7 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     # ... and as long as nothing the captured kernels bake in has changed under it: every handle counts its binds, schedule
     # changes and option changes (Engine.generation); process-wide tuning knobs are part of the key through lib.tuning_epoch()
     sig = tuple((id(e), e.generation) for e in engines) + (_lib.tuning_epoch(),)
-    ckey = (B, nchains, bool(infill), jax_mode, nT, t_hi, len(steps), int(sample_offset), int(n_glob), tuple(init.shape[1:]))
+    ckey = (B, nchains, unroll, bool(infill), jax_mode, nT, t_hi, len(steps), int(sample_offset), int(n_glob), tuple(init.shape[1:]))
     cache = model.__dict__.setdefault("_sampler_graphs", {})
     entry = cache.get("entry") if graphed else None
     reuse = entry is not None and entry["key"] == ckey and entry["sig"] == sig
@@ -726,37 +740,63 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
             ch["eng"].sample_step(ch["io"])
     elif graphed:
         cur = torch.cuda.current_stream(dev)
-        replays = len(steps)
+        replays = len(steps) - 1
+
+        def capture(ch, body):
+            ch["stream"].synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=ch["stream"]):
+                body()
+            return g
+
+        # the first iteration as plain launches on the chain's stream: the warm-up of a capture, and whatever a handle does
+        # lazily in front of a forward pass (fp8 mode: e4m3 copies of refreshed weights) happens here, outside the graphs
+        streams = model.chain_streams(len(chains))
+        for ch, st in zip(chains, streams):
+            ch["stream"] = st
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                ch["eng"].sample_step(ch["io"])
         if not reuse:
-            for ch, st in zip(chains, model.chain_streams(len(chains))):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    ch["eng"].sample_step(ch["io"])              # warm-up (also t = t_hi)
-                ch["stream"] = st
-            for ch in chains:
-                ch["stream"].synchronize()
-                ch["graph"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ch["graph"], stream=ch["stream"]):
-                    ch["eng"].sample_step(ch["io"])
+            for c, ch in enumerate(chains):
+                e, io = ch["eng"], ch["io"]
+                if unroll:          # chain 0: (output stage, next stem) x unroll; chain 1: (stem, output stage) x unroll
+                    order = (2, 1) if c == 0 else (1, 2)
+                    ch["graph"] = capture(ch, lambda e=e, io=io, order=order: [e.sample_step(io, part) for _ in range(unroll) for part in order])
+                else:
+                    ch["graph"] = capture(ch, lambda e=e, io=io: e.sample_step(io))
             entry["chains"] = chains
             cache["entry"] = entry
-            replays -= 1
-        else:
-            # the first iteration as plain launches on the chain's stream: whatever a handle does lazily in front of a forward
-            # pass (fp8 mode: e4m3 copies of refreshed weights) happens here, outside the graph, as in the run that captured it
-            for ch in chains:
-                ch["stream"].wait_stream(cur)
-                with torch.cuda.stream(ch["stream"]):
-                    ch["eng"].sample_step(ch["io"])
-            replays -= 1
         timing = os.environ.get("SMD_SAMPLER_TIMING") == "1"          # diagnostics (tools/sampler_walk_time.py): blocks the host twice
         if timing:
             torch.cuda.synchronize()
             t_loop = time.perf_counter()
-        for _ in range(replays):
-            for ch in chains:
-                with torch.cuda.stream(ch["stream"]):
-                    ch["graph"].replay()
+        if unroll:
+            A, Bc = chains
+            with torch.cuda.stream(A["stream"]):
+                A["eng"].sample_step(A["io"], 1)                      # the pipeline's prologue: chain A's stem of the next iteration
+            ev = [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]   # [chain][replay parity]
+            q, r = divmod(replays, unroll)
+            for i in range(q):
+                for c, ch in enumerate(chains):
+                    with torch.cuda.stream(ch["stream"]):
+                        if i > 0:
+                            ch["stream"].wait_event(ev[1 - c][(i - 1) & 1])     # the other chain's previous replay
+                        ch["graph"].replay()
+                        ev[c][i & 1].record(ch["stream"])
+            for _ in range(r):                                        # the iterations that do not fill a graph, as plain launches
+                with torch.cuda.stream(A["stream"]):
+                    A["eng"].sample_step(A["io"], 2)
+                    A["eng"].sample_step(A["io"], 1)
+                with torch.cuda.stream(Bc["stream"]):
+                    Bc["eng"].sample_step(Bc["io"], 1)
+                    Bc["eng"].sample_step(Bc["io"], 2)
+            # (chain A ends one stem ahead: a pass over the final state that nothing reads)
+        else:
+            for _ in range(replays):
+                for ch in chains:
+                    with torch.cuda.stream(ch["stream"]):
+                        ch["graph"].replay()
         if timing:
             t_issued = time.perf_counter()
             torch.cuda.synchronize()

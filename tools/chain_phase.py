@@ -44,7 +44,7 @@ args = ap.parse_args()
 
 dev = "cuda:0"
 L = lib.get_lib()
-a = bench.parse(["--mode", "sample", "--no-cpu-baseline", "--no-extra-configs", "--no-sampler-walk"])
+a = bench.parse(["--mode", "sample", "--no-cpu-baseline", "--no-extra-configs", "--no-sampler-walk", "--sampler-unroll", "0"])
 t_setup = time.perf_counter()
 w = bench.Workload(a, "base", args.dtype, 0, 1, dev, None)
 w.warm_up(3, False, True)

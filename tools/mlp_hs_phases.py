@@ -19,12 +19,16 @@ P = lambda t: t.data_ptr()
 part = torch.zeros(4, rows, 128, device=dev)
 lib.check(L.smd_set_tuning(b"mlp_hs_dbg", 64))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+COLD = os.environ.get("SMD_COLD") == "1"       # in-step conditions: every launch runs behind a kernel that swept 64 MB through L2
+_big = [torch.randn(16 << 20, device=dev) for _ in range(2)] if COLD else None
 for it in range(6):
+    if COLD:
+        _big[1].copy_(_big[0])
     e0.record()
     lib.check(L.smd_mlp_block_fwd_hs(P(a2), P(h), rows, P(W1t), P(b1), P(W2t), P(b2), M, P(part), st))
     e1.record()
     torch.cuda.synchronize()
-print(f"instrumented kernel: {e0.elapsed_time(e1) * 1e3:.1f} us (event pair around one launch; the shipped instantiation: tools/mlp_ab.py)")
+print(("COLD (behind a 64 MB copy) " if COLD else "") + f"instrumented kernel: {e0.elapsed_time(e1) * 1e3:.1f} us (event pair around one launch; the shipped instantiation: tools/mlp_ab.py)")
 raw = part.view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF      # [4][rows][128]
 ts = np.zeros((4, 64, 8, 36), np.int64)
 for q in range(4):
