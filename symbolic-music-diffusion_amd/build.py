@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(CSRC, "libsmd_hip.so")
 SOURCES = ["gemm_nt.hip", "gemm_nt256.hip", "gemm_tn.hip", "gemm_tn256.hip", "norm.hip", "ln128.hip", "attention.hip", "encoder_fused.hip", "diffusion.hip", "rng_jax.hip", "optim.hip",
            "engine.hip", "capi.hip"]
 HEADERS = ["smd_common.h", "smd_kernels.h", "gemm_epilogue.h", "engine.h", "rng.h", "rng_threefry.h",
-           os.path.join("..", "..", "include", "smd_hip.h")]
+           os.path.join("..", "..", "include", "smd_hip.h"), os.path.join("..", "..", "include", "smd_hip_lab.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 # SMD_ABLATIONS=1 in the environment: also compile the kernel-ablation variants (wrong results by construction; only

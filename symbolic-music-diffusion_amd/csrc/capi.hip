@@ -1,5 +1,6 @@
 // extern "C" surface of libsmd_hip.so -- see include/smd_hip.h for the contract.
 #include "../../include/smd_hip.h"
+#include "../../include/smd_hip_lab.h"
 
 #include <new>
 

@@ -54,7 +54,7 @@ class LangevinIO(C.Structure):
                 ("steps_per_level", c_i32), ("n_levels", c_i32)]
 
 
-ABI_VERSION = 4          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
+ABI_VERSION = 5          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
 
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
 _SIGS = {
@@ -162,11 +162,17 @@ _SIGS = {
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "smd_hip.h")
 
 
-def declared_symbols() -> List[str]:
-    """Every function include/smd_hip.h declares (used by the no-GPU export test)."""
-    text = open(HEADER_PATH).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(smd_[a-z0-9_]+)\s*\(", text)))
+LAB_HEADER_PATH = os.path.join(os.path.dirname(HEADER_PATH), "smd_hip_lab.h")
+
+
+def declared_symbols(lab: bool = True) -> List[str]:
+    """Every function include/smd_hip.h (and, with ``lab``, include/smd_hip_lab.h) declares (used by the no-GPU export test)."""
+    out = set()
+    for path in (HEADER_PATH, LAB_HEADER_PATH) if lab else (HEADER_PATH,):
+        text = open(path).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(smd_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def get_lib() -> C.CDLL:

@@ -145,39 +145,49 @@ def test_parity_on_trained_weights(dtype):
     print(f"[trained {dtype}] parameter drift: median {np.median(list(drift.values())):.3f}, FiLM scale kernels "
           + " ".join(f"{drift[k]:.3f}" for k in film))
     g = torch.Generator().manual_seed(31)
-    x0 = x_last
-    labels = torch.randint(1, 1001, (B,), generator=g)
-    eps = torch.randn(B, 32, C, generator=g)
-    # ---- forward + loss + gradient on the trained parameters
-    leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
-    base_model = O.make_model(leaf, ocfg)
-    seen = {}
-
-    def capturing(x, cond):
-        out = base_model(x, cond)
-        seen["pred"] = out.detach()
-        return out
-
-    loss_ref = O.diffusion_loss(x0, capturing, BETAS, labels.numpy(), eps, "none")
-    loss_ref.mean().backward()
-    eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
-    torch.cuda.synchronize()
     tol_fwd = 1e-2 if dtype == "bf16" else 5e-2
-    e_pred = rel(eng.last_pred(), seen["pred"])
-    m_eng, m_ref = float(eng.loss_per_sample().mean()), float(loss_ref.mean())
-    gv = eng.named_views(eng.grads)
-    num = sum(float((gv[k].double().cpu() - leaf[k].grad.double()).pow(2).sum()) for k in leaf)
-    den = sum(float(leaf[k].grad.double().pow(2).sum()) for k in leaf)
-    e_grad = (num / den) ** 0.5
-    # how hard the trained activations are: outlier ratio (max |x| / rms) of the 2048-wide trunk entering the output LayerNorm
-    yK = eng.debug_tensor("y", ocfg.num_mlp_layers).float()
-    print(f"[trained {dtype}] trunk before the output LayerNorm: rms {float(yK.pow(2).mean().sqrt()):.3f}, max |x| / rms "
-          f"{float(yK.abs().max() / yK.pow(2).mean().sqrt()):.1f}; |eps_hat| rms {float(seen['pred'].pow(2).mean().sqrt()):.3f}")
-    print(f"[trained {dtype}] eps_hat rel {e_pred:.3e}; loss {m_eng:.6f} vs {m_ref:.6f} ({abs(m_eng - m_ref) / m_ref:.2e}); "
-          f"gradient whole-vector rel {e_grad:.3e}")
-    assert e_pred < tol_fwd
-    assert abs(m_eng - m_ref) / m_ref < (5e-3 if dtype == "bf16" else 2.5e-2)
-    assert e_grad < (1e-2 if dtype == "bf16" else 5e-2)
+    # ---- forward + loss + gradient on the trained parameters, for two batches:
+    #   "fresh"      latents the net was NOT trained on (the bench's clip(0.25 N(0,1))): a gradient of ordinary size
+    #   "stationary" the training distribution itself: after 1500 steps the mean gradient is what is left of per-sample
+    #                gradients that cancel (|g| 0.12 against 0.9 at the start), so the per-sample bf16 error (5e-3 of each
+    #                sample's gradient, uncorrelated) is ~7x larger RELATIVE TO THE SUM: measured 4.1e-2, the same factor on every
+    #                tensor and under every engine option (profiles/r5d_trained_grad_diag.txt) -- conditioning of the quantity,
+    #                not an error of a kernel.  Asserted there: direction (cosine) and a bound with that amplification.
+    for tag, x0 in (("fresh", torch.clamp(0.25 * torch.randn(B, 32, C, generator=g), -1, 1)), ("stationary", x_last)):
+        labels = torch.randint(1, 1001, (B,), generator=g)
+        eps = torch.randn(B, 32, C, generator=g)
+        leaf = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        base_model = O.make_model(leaf, ocfg)
+        seen = {}
+
+        def capturing(x, cond):
+            out = base_model(x, cond)
+            seen["pred"] = out.detach()
+            return out
+
+        loss_ref = O.diffusion_loss(x0, capturing, BETAS, labels.numpy(), eps, "none")
+        loss_ref.mean().backward()
+        eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
+        torch.cuda.synchronize()
+        e_pred = rel(eng.last_pred(), seen["pred"])
+        m_eng, m_ref = float(eng.loss_per_sample().mean()), float(loss_ref.mean())
+        gv = eng.named_views(eng.grads)
+        num = sum(float((gv[k].double().cpu() - leaf[k].grad.double()).pow(2).sum()) for k in leaf)
+        den = sum(float(leaf[k].grad.double().pow(2).sum()) for k in leaf)
+        dot = sum(float((gv[k].double().cpu() * leaf[k].grad.double()).sum()) for k in leaf)
+        gg = sum(float(gv[k].double().pow(2).sum()) for k in leaf)
+        e_grad, cos = (num / den) ** 0.5, dot / (gg * den) ** 0.5
+        yK = eng.debug_tensor("y", ocfg.num_mlp_layers).float()
+        print(f"[trained {dtype} / {tag}] trunk before the output LayerNorm: rms {float(yK.pow(2).mean().sqrt()):.3f}, max |x| / rms "
+              f"{float(yK.abs().max() / yK.pow(2).mean().sqrt()):.1f}; |eps_hat| rms {float(seen['pred'].pow(2).mean().sqrt()):.3f}")
+        print(f"[trained {dtype} / {tag}] eps_hat rel {e_pred:.3e}; loss {m_eng:.6f} vs {m_ref:.6f} ({abs(m_eng - m_ref) / m_ref:.2e}); "
+              f"|g| {den ** 0.5:.4f}; gradient whole-vector rel {e_grad:.3e}, cosine {cos:.6f}")
+        assert e_pred < tol_fwd
+        assert abs(m_eng - m_ref) / m_ref < (5e-3 if dtype == "bf16" else 2.5e-2)
+        if tag == "fresh":
+            assert e_grad < (1e-2 if dtype == "bf16" else 5e-2)
+        else:
+            assert cos > (0.998 if dtype == "bf16" else 0.98) and e_grad < (8e-2 if dtype == "bf16" else 2.5e-1)
     # ---- three reverse steps with explicit draws (utils/ebm_utils.py:327-394) on the trained parameters
     init = torch.randn(B, 32, C, generator=g)
     zs = {t: torch.randn(B, 32, C, generator=g) for t in (999, 998, 997)}
@@ -190,7 +200,7 @@ def test_parity_on_trained_weights(dtype):
     assert e_state < 1e-2
     assert e_slope < tol_fwd
     # ---- and a late, low-noise step where the x0 prediction matters (t = 20 .. 18), teacher-forced from a mid-walk state
-    xs = torch.clamp(x0 + 0.05 * torch.randn(B, 32, C, generator=g), -1.5, 1.5)
+    xs = torch.clamp(x_last + 0.05 * torch.randn(B, 32, C, generator=g), -1.5, 1.5)
     z2 = {t: torch.randn(B, 32, C, generator=g) for t in (20, 19, 18)}
     with torch.no_grad():
         ref2, _, _ = O.diffusion_dynamics(O.make_model(p, ocfg), BETAS, xs, lambda t: z2[t], t_start=20, t_stop=18)
