@@ -84,6 +84,7 @@ def parse(argv=None):
     ap.add_argument("--sampler-unroll", type=int, default=-1,
                     help="two chains: reverse steps per captured graph of the pipelined walk (-1: the largest of 8, 4, 2, 1 that divides "
                          "--steps, capped by smd_amd's own default; 0: two free-running one-step graphs, the round-4 arrangement)")
+    ap.add_argument("--chain-opt", action="append", default=[], help="engine option key=value for the sampler's chain handles (A/B runs)")
     ap.add_argument("--no-roofline-microbench", action="store_true",
                     help="skip the back-to-back launches of the dominant kernel (profiling runs: the trace then holds the timed loops only)")
     return ap.parse_args(argv)
@@ -267,6 +268,9 @@ class Workload:
             nk_d = torch.from_numpy(nk.view(np.int32).copy()).to(dev)
         self._nk_d = nk_d
         for c, eng in enumerate(engines):
+            for kv in a.chain_opt:
+                k, _, v = kv.partition("=")
+                eng.set_option(k, int(v))
             eng.set_schedule(betas, with_sampler=True)
             eng.bind(hB, training=False)
             eng.prepare_sampler()
