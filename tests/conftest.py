@@ -34,3 +34,22 @@ def pytest_collection_modifyitems(config, items):
 def dev():
     import torch
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _oracle_threads(request):
+    """Host threads for the CPU oracle.  Most parity tests evaluate it on a handful of sequences (64-row matrices): on the GPU
+    box's 64 hardware threads the fork / join of every small torch op then dominates (a 1000-step fp64 walk: 400 s on 64
+    threads, 18 s on 8).  Default 16; a module that runs the oracle at B = 256 sets ORACLE_THREADS = 64."""
+    try:
+        import torch
+    except Exception:
+        yield
+        return
+    before = torch.get_num_threads()
+    want = int(getattr(request.module, "ORACLE_THREADS", 16))
+    torch.set_num_threads(max(1, min(want, os.cpu_count() or 1)))
+    try:
+        yield
+    finally:
+        torch.set_num_threads(before)

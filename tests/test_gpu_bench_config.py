@@ -17,6 +17,7 @@ import torch
 import ddpm_oracle as O
 
 pytestmark = pytest.mark.gpu
+ORACLE_THREADS = 64          # the oracle runs at B = 256 here (tests/conftest.py)
 
 BETAS = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
 CONFIGS = {"base": dict(L=6, H=8, K=2), "large": dict(L=8, H=16, K=3)}

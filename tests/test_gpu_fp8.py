@@ -10,6 +10,7 @@ import torch
 import ddpm_oracle as O
 
 pytestmark = pytest.mark.gpu
+ORACLE_THREADS = 64          # the oracle runs at B = 256 here (tests/conftest.py)
 
 BETAS = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
 

@@ -296,6 +296,13 @@ def _dp_worker(rank, world, port, tmp):
         other = [torch.empty_like(v) for _ in range(world)]
         dist.all_gather(other, mine_bytes)
         assert all(torch.equal(o, mine_bytes) for o in other), f"rs_ag {kw}: ranks hold different reduced gradients"
+    # what the bench line reports about the exchange: backend, world size, shape, a count of the collectives issued
+    d = comm.describe()
+    assert d["backend"] == "gloo" and d["world_size"] == world and d["algorithm"] == "all_reduce" and d["layer_buckets"] is False
+    c0 = comm.collectives
+    v = grads(slice(rank * half, (rank + 1) * half)).float().clone()
+    comm.reduce_async(v[head:]); comm.reduce_async(v[:head]); comm.wait()
+    assert comm.collectives - c0 == 2 * comm.buckets and comm.exposed_comm_us() is None      # CPU tensors: nothing to time
     flat = torch.full((10,), float(rank))
     comm.broadcast_params(flat)
     assert float(flat.sum()) == 0.0
@@ -318,7 +325,7 @@ def test_data_parallel_gradient_exchange_gloo(tmp_path):
 def test_custom_ops_are_registered_and_have_no_cpu_path():
     """north_star: 'Python host code calling hand-written HIP kernels through PyTorch-ROCm custom ops (C-ABI)'."""
     import smd_amd.ops as ops  # noqa: F401
-    for name in ("eps_forward", "gemm_bf16_nt", "ddpm_reverse_step_", "q_sample"):
+    for name in ("eps_forward", "eps_forward_train", "eps_backward", "gemm_bf16_nt", "ddpm_reverse_step_", "q_sample"):
         assert hasattr(torch.ops.smd_amd, name)
     with pytest.raises(RuntimeError, match="GPU only"):
         torch.ops.smd_amd.gemm_bf16_nt(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16),
@@ -331,6 +338,10 @@ def test_custom_ops_are_registered_and_have_no_cpu_path():
         assert tuple(out.shape) == (256, 512) and out.dtype == torch.bfloat16
         e = torch.ops.smd_amd.eps_forward(torch.empty(4, 32, 512), torch.empty(4, 1, 1), 0)
         assert tuple(e.shape) == (4, 32, 512)
+        # the differentiable form: the output carries an autograd edge to the flat parameter buffer (registered formula)
+        pr = torch.empty(1000, requires_grad=True)
+        et = torch.ops.smd_amd.eps_forward_train(torch.empty(4, 32, 512), torch.empty(4, 1, 1), pr, 0)
+        assert tuple(et.shape) == (4, 32, 512) and et.requires_grad
         xt, s = torch.ops.smd_amd.q_sample(torch.empty(4, 32, 42), torch.empty(1001), torch.empty(4, dtype=torch.int32),
                                            torch.empty(4, 32, 42))
         assert tuple(xt.shape) == (128, 42) and tuple(s.shape) == (4,)
@@ -421,3 +432,50 @@ def test_shipped_lds_layouts_are_conflict_free_under_the_real_lane_groups():
     assert old["S3 A fragments (64-B rows)"] == 4 and old["dz B fragments (64-B rows)"] == 4
     assert extra(m.attn_block_fwd(False))["residual rows, fp32 (epilogue reads)"] == 60
     assert extra(m.attn_block_bwd(lambda r: r))["transposing reads of k, q, dO (first rows)"] == 2
+
+
+def test_build_identity_is_content_addressed(tmp_path, monkeypatch):
+    """build.py: the library's staleness is decided by a hash of the sources / headers / flags it was built from (embedded as
+    SMD_BUILD_ID=<16 hex> and returned by smd_build_id()), never by file times."""
+    import smd_amd.build as b
+    sid = b.source_id()
+    assert len(sid) == 16 and int(sid, 16) >= 0 and b.source_id() == sid
+    # the id moves with the flags (experiment builds) ...
+    monkeypatch.setattr(b, "FLAGS", b.FLAGS + ["-DSMD_SOMETHING"])
+    assert b.source_id() != sid
+    monkeypatch.undo()
+    assert b.source_id() == sid
+    # ... and is read back from a binary without loading it
+    f = tmp_path / "lib.so"
+    f.write_bytes(b"\x7fELF junk SMD_BUILD_ID=0123456789abcdef more junk")
+    assert b.built_id(str(f)) == "0123456789abcdef"
+    f.write_bytes(b"no id in here")
+    assert b.built_id(str(f)) == "" and b.built_id(str(tmp_path / "missing.so")) == ""
+    if os.path.exists(b.LIB_PATH):
+        import smd_amd.lib as lib
+        assert lib.get_lib().smd_build_id().decode() == b.built_id() == sid        # the shipped library is this tree's
+        os.utime(b.LIB_PATH, (1, 1))                                               # an ancient file time changes nothing
+        assert not b.is_stale()
+
+
+def test_stable_and_lab_headers_partition_the_exports():
+    """include/smd_hip.h is the surface a maintainer binds; tuning knobs, debug views and probes live in smd_hip_lab.h."""
+    import smd_amd.lib as lib
+    stable, both = set(lib.declared_symbols(lab=False)), set(lib.declared_symbols())
+    lab = both - stable
+    assert lab == {"smd_set_tuning", "smd_engine_debug_snapshot_bytes", "smd_engine_debug_snapshots", "smd_engine_debug_tensor",
+                   "smd_probe_clock", "smd_probe_l2_warm", "smd_probe_tr_read"}
+    assert {"smd_engine_sample_step_part", "smd_engine_forward_train", "smd_engine_backward_from", "smd_build_id",
+            "smd_stream_create_xcd_mask"} <= stable
+    assert both == set(lib._SIGS)                                                   # the ctypes table covers exactly the two headers
+
+
+def test_sampler_pipeline_switches(monkeypatch):
+    import smd_amd.ncsn as N
+    monkeypatch.delenv("SMD_SAMPLER_PIPELINE", raising=False)
+    monkeypatch.delenv("SMD_SAMPLER_UNROLL", raising=False)
+    assert N._sampler_pipeline_unroll() == 4
+    monkeypatch.setenv("SMD_SAMPLER_UNROLL", "8")
+    assert N._sampler_pipeline_unroll() == 8
+    monkeypatch.setenv("SMD_SAMPLER_PIPELINE", "0")
+    assert N._sampler_pipeline_unroll() == 0
