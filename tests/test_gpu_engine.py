@@ -946,18 +946,20 @@ def test_train_step_arbitrary_objective_through_autograd():
         train_step(twice, x0, opt, BETAS, N.PRNGKey(0), 1e-3)
 
 
-@pytest.mark.parametrize("unroll", [1, 4, 8])
-def test_pipelined_two_chain_walk_is_the_free_running_walk_bitwise(unroll, monkeypatch):
+@pytest.mark.parametrize("arch,unroll", [("TransformerDDPM", 1), ("TransformerDDPM", 4), ("TransformerDDPM", 8), ("DenseDDPM", 4)])
+def test_pipelined_two_chain_walk_is_the_free_running_walk_bitwise(arch, unroll, monkeypatch):
     """The default two-chain walk is software-pipelined (chain A: output stage + reverse update of iteration k, stem of k + 1;
     chain B: stem, output stage of k; `unroll` iterations per captured graph, a cross-chain event per replay; remainder
     iterations as plain launches: smd_engine_sample_step_part).  Per chain it launches exactly the kernels of the one-step
     graphs in the same order, so state, collection and metrics must be BITWISE those of the free-running arrangement
     (SMD_SAMPLER_PIPELINE=0), for walk lengths that do and do not fill the last graph."""
     import smd_amd.ncsn as N
-    _, _, model = make(C=512, L=2, K=1)
-    B = 128
-    init = torch.randn(B, 32, 512, generator=torch.Generator().manual_seed(3))
+    _, _, model = make(arch, C=512, L=2, K=1)
+    B = 128 if arch == "TransformerDDPM" else 512                  # two chains need 256-row multiples per chain (DenseDDPM: S = 1)
+    shape = (32, 512) if arch == "TransformerDDPM" else (512,)
+    init = torch.randn(B, *shape, generator=torch.Generator().manual_seed(3))
     key = N.PRNGKey(21)
+    assert N._sampler_chains(model, B, True) == 2
     for t_stop in (1000 - 1 - 2 * unroll, 1000 - 27):             # 1 + 2 * unroll iterations (fills the graphs), 27 (a remainder)
         monkeypatch.setenv("SMD_SAMPLER_PIPELINE", "0")
         ref = N.diffusion_dynamics(key, model, BETAS, init, t_stop=t_stop)
