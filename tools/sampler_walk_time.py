@@ -20,16 +20,16 @@ for i in range(4):
     print(f"sampler_walk call {i}: {dt:.4f} s = {1000 / dt:.0f} steps/s, finite {bool(torch.isfinite(gen).all())}{extra}")
     del gen, coll
 
-# the same cached graphs replayed in blocks of 100 (what bench.py's sample loop does), t restarted before each block
-import smd_amd.lib as lib
-ent = model._sampler_graphs["entry"]
-for blk in range(6):
-    for ch in ent["chains"]:
-        lib.check(lib.get_lib().smd_set_timestep(ch["t_ptr"].data_ptr(), 999 if blk % 2 == 0 else 500, ch["stream"].cuda_stream))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(100):
-        for ch in ent["chains"]:
-            with torch.cuda.stream(ch["stream"]):
-                ch["graph"].replay()
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"sampler_walk block {blk} (t from {999 if blk % 2 == 0 else 500}): {dt / 100 * 1e6:.0f} us/step")
+# the walk under the other chain arrangements (graphs are re-captured when the arrangement changes): free-running one-step graphs
+# (round 4), pipelined with U steps per graph
+for env in ({"SMD_SAMPLER_PIPELINE": "0"}, {"SMD_SAMPLER_UNROLL": "1"}, {"SMD_SAMPLER_UNROLL": "8"}, {"SMD_SAMPLER_UNROLL": "16"}, {}):
+    for k in ("SMD_SAMPLER_PIPELINE", "SMD_SAMPLER_UNROLL"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    ts = []
+    for i in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        gen, coll, _ = N.sample(model, betas, N.PRNGKey(21 + i), (32, 512), num_samples=256, sampling="ddpm")
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        del gen, coll
+    print(f"sampler_walk {env or 'default (pipelined, 4 steps per graph)'}: " + " ".join(f"{t:.4f}" for t in ts) + f" s -> {1000 / min(ts):.0f} steps/s")
