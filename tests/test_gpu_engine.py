@@ -971,3 +971,52 @@ def test_pipelined_two_chain_walk_is_the_free_running_walk_bitwise(arch, unroll,
         for u, v, w_ in zip(ref, got, again):
             assert torch.equal(u, v) and torch.equal(u, w_)
         assert model._sampler_graphs["entry"]["key"][2] == unroll
+
+
+@pytest.mark.parametrize("arch,C,K,dtype", [("TransformerDDPM", 512, 2, "bf16"), ("TransformerDDPM", 146, 3, "bf16"), ("DenseDDPM", 512, 2, "bf16"),
+                                             ("TransformerDDPM", 512, 2, "fp8")])
+def test_sample_step_parts_compose_to_the_whole_step_bitwise(arch, C, K, dtype):
+    """smd_engine_sample_step_part: part 1 (the stem, plus the first `sample_split` LayerNorm + Dense half-blocks of the output stage)
+    followed by part 2 (the rest + the fused reverse update) IS smd_engine_sample_step, for every split point, on every
+    architecture and in fp8 mode: same kernels, same order, same buffers."""
+    import smd_amd.lib as lib
+    import smd_amd.ncsn as N
+    from smd_amd.engine import NetConfig
+    B = 8 if arch == "TransformerDDPM" else 256
+    cfg = NetConfig(architecture=arch, data_channels=C, seq_len=32, num_layers=2, num_mlp_layers=K, num_timesteps=1000, dtype=dtype)
+    if dtype == "fp8":
+        B = 8 * 8                                                  # the e4m3 GEMMs want 256-row multiples
+    model = N.Model(cfg, "cuda:0", seed=5)
+    eng = model.engine
+    eng.set_schedule(BETAS, with_sampler=True)
+    eng.bind(B, training=False)
+    eng.prepare_sampler()
+    shape = (B, C) if arch == "DenseDDPM" else (B, 32, C)
+    x = torch.empty(*shape, device="cuda")
+    t_ptr = torch.zeros(1, dtype=torch.int32, device="cuda")
+    met = torch.zeros(1000, B, 3, device="cuda")
+    io = lib.SampleIO()
+    io.x, io.t_ptr, io.metrics_partial = x.data_ptr(), t_ptr.data_ptr(), met.data_ptr()
+    io.seed_lo, io.seed_hi, io.sample_offset = 11, 0, 0
+
+    def walk(split, steps=3):
+        eng.set_option("sample_split", max(split, 0))
+        eng.init_state(x, 77, 0)
+        t_ptr.fill_(999)
+        met.zero_()
+        for _ in range(steps):
+            if split < 0:
+                eng.sample_step(io)
+            else:
+                eng.sample_step(io, 1)
+                eng.sample_step(io, 2)
+        torch.cuda.synchronize()
+        return x.clone(), met.clone(), int(t_ptr.item())
+
+    ref = walk(-1)
+    assert ref[2] == 996 and float(ref[0].abs().max()) > 0
+    for split in range(0, 2 * K + 1):                              # 2 K = the whole output stage but its final norm + Dense in part 1
+        got = walk(split)
+        assert got[2] == 996 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"split {split}"
+    with pytest.raises(ValueError):
+        eng.sample_step(io, 3)
