@@ -623,8 +623,11 @@ __global__ __launch_bounds__(64 * NWV) void mlp_hs_fwd_kernel(MlpHsArgs a) {
         for (int mt = 0; mt < 2; ++mt) {
           const float bb[4] = {bcur[mt].x, bcur[mt].y, bcur[mt].z, bcur[mt].w};
           bf16x4_t uu;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) uu[e] = f2bf(geluf_(z[s][mt][e] + bb[e]));
+          {   // two activations per VALU instruction (smd_common.h geluf2_: bit-identical to geluf_)
+            const f32x2_t g01 = geluf2_(f32x2_t{z[s][mt][0], z[s][mt][1]} + f32x2_t{bb[0], bb[1]});
+            const f32x2_t g23 = geluf2_(f32x2_t{z[s][mt][2], z[s][mt][3]} + f32x2_t{bb[2], bb[3]});
+            uu[0] = f2bf(g01.x); uu[1] = f2bf(g01.y); uu[2] = f2bf(g23.x); uu[3] = f2bf(g23.y);
+          }
           const int hid = hg * 32 + mt * 16 + 4 * g;
           *reinterpret_cast<bf16x4_t*>(smem + HS_TILE + ((s_lo + s) * 32 + tok) * 256 + (((hid >> 3) ^ (tok & 15)) << 4) + (hid & 7) * 2) = uu;
         }
@@ -867,11 +870,12 @@ __global__ __launch_bounds__(512) void mlp_hs_bwd_kernel(MlpHsBwdArgs a) {
           // hidden of element e: c*32 + ht*16 + 4g + e, token = tok
           bf16x4_t u4, d4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float gz, dgz;
-            gelu_fwd_grad_(z[e] + bb[e], gz, dgz);
-            u4[e] = f2bf(gz);
-            d4[e] = f2bf(du[e] * dgz);
+          for (int e = 0; e < 4; e += 2) {   // two activations per VALU instruction (gelu_fwd_grad2_: bit-identical to the scalar form)
+            f32x2_t gz, dgz;
+            gelu_fwd_grad2_(f32x2_t{z[e], z[e + 1]} + f32x2_t{bb[e], bb[e + 1]}, gz, dgz);
+            const f32x2_t dd = f32x2_t{du[e], du[e + 1]} * dgz;
+            u4[e] = f2bf(gz.x); u4[e + 1] = f2bf(gz.y);
+            d4[e] = f2bf(dd.x); d4[e + 1] = f2bf(dd.y);
           }
           const int piece = ht * 2 + (g >> 1);
           const int off = (s * 32 + tok) * 64 + ((piece ^ tswz) << 4) + (g & 1) * 8;
