@@ -9,7 +9,10 @@ than N GPUs or when WORLD_SIZE disagrees with --gpus: the line it prints always 
 
 One "step" = one train_step (q-sample + eps-net forward + backward + clip + Adam, + RCCL gradient
 all-reduce when N > 1) followed by one reverse-diffusion step (eps-net forward + fused posterior
-update), each on a batch of --batch sequences per GPU.  Two denoising evaluations per step, so
+update), each on a batch of --batch sequences per GPU.  The reverse steps run as ncsn.diffusion_dynamics runs them: the batch as
+two half-batch chains, software-pipelined (chain A: output stage + reverse update of step k and the stem of step k + 1, chain B: stem
+and output stage of step k; U steps per captured hipGraph, a cross-chain event per replay; U = the largest of 8, 4, 2, 1 that
+divides --steps, capped at the package default 4) -- DESIGN.md section 5.  Two denoising evaluations per step, so
 ``value`` = N * 2K / max-over-ranks(time of K steps): whole-job denoising-steps/sec (weak scaling: the
 per-GPU batch is fixed).  Inputs are resident in HBM before the timed region.  The timed region is repeated
 ``--repeats`` times (blocks of exactly K train steps + K reverse steps, each bracketed by barrier + synchronize);
