@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 5   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots; 4: one-sweep optimiser, "opt_overlap", smd_engine_join_update; 5: smd_build_id, smd_engine_sample_step_part, smd_engine_forward_train / backward_from, smd_stream_create_xcd_mask; the lab hooks (tuning knobs, debug tensors, probes) moved to smd_hip_lab.h -- this header is the stable surface */
+#define SMD_ABI_VERSION 5   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots; 4: one-sweep optimiser, "opt_overlap", smd_engine_join_update; 5: smd_build_id, smd_engine_sample_step_part, smd_engine_forward_train / backward_from; the lab hooks (tuning knobs, debug tensors, probes) moved to smd_hip_lab.h -- this header is the stable surface */
 
 typedef uint16_t smd_bf16;
 typedef struct smd_engine smd_engine;
@@ -380,14 +380,6 @@ int smd_ddpm_reverse_step(float* x, const float* eps_hat, int B, int S, int C, c
                           const int32_t* t_ptr, const float* z_in, uint32_t seed_lo, uint32_t seed_hi,
                           uint32_t sample_offset, float* metrics_partial, float* collection,
                           const int32_t* slot_table, void* stream);
-/* A HIP stream (returned as void*) whose kernels are dispatched only to the XCDs set in xcd_mask (bit x = XCD x of the 8):
- * hipExtStreamCreateWithCUMask with the CUs of those XCDs.  The host walks the two concurrent half-batch sampling chains
- * (utils/ebm_utils.py:399-401 over two independent halves of the batch) on streams of XCDs 0-3 and 4-7: each chain's 128-tile
- * GEMMs then own 128 CUs and four private L2s, whatever the other chain is doing.  layout 0 is the mapping of mask bits to
- * XCDs the driver implements (bit i -> XCD i % 8, tools/cumask_probe.hip); layout 1 (bit i -> XCD i / 32) exists for that
- * probe only.  The stream belongs to the caller: smd_stream_destroy. */
-int smd_stream_create_xcd_mask(uint32_t xcd_mask, int layout, void** stream_out);
-int smd_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,14 @@ int smd_engine_debug_tensor(const smd_engine* e, const char* name, int index, co
  * between equivalent kernels for A/B runs; unknown keys return < 0. */
 int smd_set_tuning(const char* key, int value);
 
+/* lab probe: a HIP stream (returned as void*) created with hipExtStreamCreateWithCUMask(mask_words[0 .. n_words), one bit per CU).
+ * Measured on MI355X / ROCm 7.2 (tools/cumask_probe.hip, profiles/r5a_cumask_probe.txt): mask bit i belongs to XCC i % 8; an XCC
+ * whose share of the mask is EMPTY is not masked at all (a single set bit leaves 7 x 32 + 1 = 225 CUs), so a stream cannot be kept
+ * off an XCD -- only a fraction of EVERY XCC's CUs can be selected (bits 0..127 = half of each).  Graph launches honour the launch
+ * stream's mask like plain launches.  tools/chain_phase.py used it to show that halving every XCC between the two sampling chains
+ * buys nothing; the product does not use it. */
+int smd_probe_stream_create_cu_mask(const uint32_t* mask_words, int n_words, void** stream_out);
+int smd_probe_stream_destroy(void* stream);
 /* lab probe: `blocks` one-wave workgroups spin for ~spin_us; out[8 * b + ..] = XCC id, HW_ID, shader-clock ticks (2 words),
  * 100 MHz ticks (2 words), start time in 100 MHz ticks (2 words) -- where a stream runs and at which clock */
 int smd_probe_clock(uint32_t* out, int blocks, int spin_us, void* stream);

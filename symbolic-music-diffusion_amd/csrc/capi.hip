@@ -426,31 +426,18 @@ int smd_ddpm_reverse_step(float* x, const float* eps_hat, int Bn, int Sn, int C,
 
 int smd_probe_tr_read(const smd_bf16* image, smd_bf16* out, void* stream) { return launch_probe_tr_read(B(image), B(out), S(stream)); }
 
-// ---- streams pinned to a subset of the XCDs (the two sampling chains: one half of the chip each)
-int smd_stream_create_xcd_mask(uint32_t xcd_mask, int layout, void** stream_out) {
-  SMD_ARG_CHECK(stream_out, "smd_stream_create_xcd_mask: null argument");
-  SMD_ARG_CHECK((xcd_mask & 0xFFu) != 0 && (xcd_mask >> 8) == 0, "smd_stream_create_xcd_mask: xcd_mask=0x%x must select 1..8 of the 8 XCDs", xcd_mask);
-  SMD_ARG_CHECK(layout == 0 || layout == 1, "smd_stream_create_xcd_mask: layout=%d (0 interleaved, 1 blocked)", layout);
-  // 256 mask bits, one per CU.  layout 0: bit i belongs to XCD i % 8 (the KFD walks the mask round-robin over the XCCs);
-  // layout 1: bit i belongs to XCD i / 32 (lab only: tools/cumask_probe decides which one the driver implements)
-  uint32_t words[8];
-  for (int w = 0; w < 8; ++w) {
-    uint32_t v = 0;
-    for (int b = 0; b < 32; ++b) {
-      const int i = w * 32 + b;
-      const int xcd = layout == 0 ? (i & 7) : (i >> 5);
-      if ((xcd_mask >> xcd) & 1u) v |= 1u << b;
-    }
-    words[w] = v;
-  }
+// ---- lab probe: a stream restricted by a raw CU mask (hipExtStreamCreateWithCUMask).  What the mask can express on this part is
+// documented in include/smd_hip_lab.h (tools/cumask_probe.hip: bit i belongs to XCC i % 8; an XCC whose share is empty is NOT masked).
+int smd_probe_stream_create_cu_mask(const uint32_t* mask_words, int n_words, void** stream_out) {
+  SMD_ARG_CHECK(mask_words && stream_out && n_words >= 1 && n_words <= 8, "smd_probe_stream_create_cu_mask: bad argument");
   hipStream_t st = nullptr;
-  const hipError_t err = hipExtStreamCreateWithCUMask(&st, 8, words);
+  const hipError_t err = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words);
   if (err != hipSuccess) { smd_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(err)); return (int)err; }
   *stream_out = reinterpret_cast<void*>(st);
   return 0;
 }
-int smd_stream_destroy(void* stream) {
-  SMD_ARG_CHECK(stream, "smd_stream_destroy: null stream");
+int smd_probe_stream_destroy(void* stream) {
+  SMD_ARG_CHECK(stream, "smd_probe_stream_destroy: null stream");
   const hipError_t err = hipStreamDestroy(S(stream));
   if (err != hipSuccess) { smd_set_error("hipStreamDestroy: %s", hipGetErrorString(err)); return (int)err; }
   return 0;

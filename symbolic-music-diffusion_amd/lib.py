@@ -153,8 +153,8 @@ _SIGS = {
     "smd_ddpm_reverse_step": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_u32,
                                         c_u32, c_u32, c_void, c_void, c_void, c_void]),
     "smd_probe_tr_read": (C.c_int, [c_void, c_void, c_void]),
-    "smd_stream_create_xcd_mask": (C.c_int, [c_u32, C.c_int, C.POINTER(c_void)]),
-    "smd_stream_destroy": (C.c_int, [c_void]),
+    "smd_probe_stream_create_cu_mask": (C.c_int, [C.POINTER(c_u32), C.c_int, C.POINTER(c_void)]),
+    "smd_probe_stream_destroy": (C.c_int, [c_void]),
     "smd_probe_clock": (C.c_int, [c_void, C.c_int, C.c_int, c_void]),
     "smd_probe_l2_warm": (C.c_int, [c_void, c_i64, c_void, c_void]),
 }

@@ -464,9 +464,8 @@ def test_stable_and_lab_headers_partition_the_exports():
     stable, both = set(lib.declared_symbols(lab=False)), set(lib.declared_symbols())
     lab = both - stable
     assert lab == {"smd_set_tuning", "smd_engine_debug_snapshot_bytes", "smd_engine_debug_snapshots", "smd_engine_debug_tensor",
-                   "smd_probe_clock", "smd_probe_l2_warm", "smd_probe_tr_read"}
-    assert {"smd_engine_sample_step_part", "smd_engine_forward_train", "smd_engine_backward_from", "smd_build_id",
-            "smd_stream_create_xcd_mask"} <= stable
+                   "smd_probe_clock", "smd_probe_l2_warm", "smd_probe_tr_read", "smd_probe_stream_create_cu_mask", "smd_probe_stream_destroy"}
+    assert {"smd_engine_sample_step_part", "smd_engine_forward_train", "smd_engine_backward_from", "smd_build_id"} <= stable
     assert both == set(lib._SIGS)                                                   # the ctypes table covers exactly the two headers
 
 

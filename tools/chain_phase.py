@@ -4,8 +4,9 @@ One process, the bench's own chains and captured graphs (bench.Workload), replay
   plain      the two torch streams of bench.py
   delay=X    chain B starts X us behind chain A (does the rate depend on the PHASE between the chains?)
   prio       two high-priority streams
-  xcd        chain A on XCDs 0-3, chain B on XCDs 4-7 (smd_stream_create_xcd_mask, layout 0 = interleaved mask bits)
-  xcdblk     the same with layout 1 (blocked mask bits) -- tools/cumask_probe says which layout is the real one
+  xcd        chain A masked to XCCs 0-3, chain B to 4-7 under the interleaved rule (smd_probe_stream_create_cu_mask) -- which the
+             probe showed to leave the OTHER XCCs unmasked: effectively no mask
+  xcdblk     mask bits 0..127 / 128..255: half of EVERY XCC's CUs per chain (the only partition a CU mask can express)
   one        both chains on ONE stream (no overlap at all: the sequential reference)
   pipe1      the software pipeline: ONE captured graph per step pair, forked over two streams -- chain A runs (output stage +
              reverse update of step k, stem of step k+1), chain B runs (stem of step k, output stage of step k): one chain's
@@ -53,8 +54,15 @@ print(f"# {args.tag}: setup + warm-up + capture {time.perf_counter() - t_setup:.
 
 
 def masked_stream(mask, layout):
+    """layout 0: mask bit i set for the XCCs in `mask` under the interleaved rule (bit i -> XCC i % 8) -- which, as the probe showed,
+    leaves the other XCCs UNMASKED; layout 1: bits 32 x .. 32 x + 31 for every x in `mask` (a fraction of every XCC's CUs)"""
+    words = (C.c_uint32 * 8)()
+    for i in range(256):
+        x = (i & 7) if layout == 0 else (i >> 5)
+        if (mask >> x) & 1:
+            words[i >> 5] |= 1 << (i & 31)
     p = C.c_void_p()
-    lib.check(L.smd_stream_create_xcd_mask(mask, layout, C.byref(p)), "stream_create_xcd_mask")
+    lib.check(L.smd_probe_stream_create_cu_mask(words, 8, C.byref(p)), "stream_create_cu_mask")
     return torch.cuda.ExternalStream(p.value, device=dev)
 
 
