@@ -11,8 +11,8 @@ One "step" = one train_step (q-sample + eps-net forward + backward + clip + Adam
 all-reduce when N > 1) followed by one reverse-diffusion step (eps-net forward + fused posterior
 update), each on a batch of --batch sequences per GPU.  The reverse steps run as ncsn.diffusion_dynamics runs them: the batch as
 two half-batch chains, software-pipelined (chain A: output stage + reverse update of step k and the stem of step k + 1, chain B: stem
-and output stage of step k; U steps per captured hipGraph, a cross-chain event per replay; U = the largest of 8, 4, 2, 1 that
-divides --steps, capped at the package default 4) -- DESIGN.md section 5.  Two denoising evaluations per step, so
+and output stage of step k; U steps per captured hipGraph, a cross-chain event per replay; U = the largest divisor of --steps
+up to the package default 8: 5 for --steps 20) -- DESIGN.md section 5.  Two denoising evaluations per step, so
 ``value`` = N * 2K / max-over-ranks(time of K steps): whole-job denoising-steps/sec (weak scaling: the
 per-GPU batch is fixed).  Inputs are resident in HBM before the timed region.  The timed region is repeated
 ``--repeats`` times (blocks of exactly K train steps + K reverse steps, each bracketed by barrier + synchronize);
@@ -85,8 +85,8 @@ def parse(argv=None):
     ap.add_argument("--sampler-chains", type=int, default=2, choices=[1, 2],
                     help="graph-replayed sampling as two concurrent half-batch chains (default) or one chain")
     ap.add_argument("--sampler-unroll", type=int, default=-1,
-                    help="two chains: reverse steps per captured graph of the pipelined walk (-1: the largest of 8, 4, 2, 1 that divides "
-                         "--steps, capped by smd_amd's own default; 0: two free-running one-step graphs, the round-4 arrangement)")
+                    help="two chains: reverse steps per captured graph of the pipelined walk (-1: the largest U <= smd_amd's own default (8) that "
+                         "divides --steps; 0: two free-running one-step graphs, the round-4 arrangement)")
     ap.add_argument("--chain-opt", action="append", default=[], help="engine option key=value for the sampler's chain handles (A/B runs)")
     ap.add_argument("--no-roofline-microbench", action="store_true",
                     help="skip the back-to-back launches of the dominant kernel (profiling runs: the trace then holds the timed loops only)")
@@ -301,7 +301,7 @@ class Workload:
         if nchains == 2:
             want = N._sampler_pipeline_unroll() if a.sampler_unroll < 0 else a.sampler_unroll
             if want > 0:
-                self.unroll = max(u for u in (8, 4, 2, 1) if u <= want and a.steps % u == 0)
+                self.unroll = max(u for u in range(1, 9) if u <= want and a.steps % u == 0)
         self._ev = [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]
         self._replays = 0
 

@@ -594,10 +594,11 @@ def _sampler_chains(model: "Model", B: int, graphed: bool) -> int:
 
 def _sampler_pipeline_unroll() -> int:
     """Iterations per captured graph of the pipelined two-chain walk (0: the two chains free-running as one-step graphs, the
-    round-4 arrangement; SMD_SAMPLER_PIPELINE=0 / SMD_SAMPLER_UNROLL=U in the environment)."""
+    round-4 arrangement; SMD_SAMPLER_PIPELINE=0 / SMD_SAMPLER_UNROLL=U in the environment).  Default 8: the join and the launch
+    gap of both chains coincide once per replay -- 1000-step walk 0.552 / 0.535 / 0.5325 / 0.531 s at 1 / 4 / 8 / 16 (profiles/r5m_sampler_walk.txt)."""
     if os.environ.get("SMD_SAMPLER_PIPELINE", "1") == "0":
         return 0
-    return max(1, int(os.environ.get("SMD_SAMPLER_UNROLL", "4")))
+    return max(1, int(os.environ.get("SMD_SAMPLER_UNROLL", "8")))
 
 
 def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=None, denoise=None, infill=False,

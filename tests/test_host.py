@@ -473,8 +473,8 @@ def test_sampler_pipeline_switches(monkeypatch):
     import smd_amd.ncsn as N
     monkeypatch.delenv("SMD_SAMPLER_PIPELINE", raising=False)
     monkeypatch.delenv("SMD_SAMPLER_UNROLL", raising=False)
-    assert N._sampler_pipeline_unroll() == 4
-    monkeypatch.setenv("SMD_SAMPLER_UNROLL", "8")
     assert N._sampler_pipeline_unroll() == 8
+    monkeypatch.setenv("SMD_SAMPLER_UNROLL", "4")
+    assert N._sampler_pipeline_unroll() == 4
     monkeypatch.setenv("SMD_SAMPLER_PIPELINE", "0")
     assert N._sampler_pipeline_unroll() == 0
