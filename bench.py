@@ -168,7 +168,8 @@ def dp_dry_run(a, rank, world, dev, dist, comm):
 
 
 def cpu_baseline(cfg_name: str, batch: int):
-    """Oracle on the host cores: 2 train steps + 4 reverse steps at the benchmark batch size (a bounded sample, ~20 s)."""
+    """Oracle on the host cores: 5 train steps + 10 reverse steps at the benchmark batch size (~60 s on
+    64 threads, a bounded sample: the batch shrinks on slower hosts)."""
     import torch
     import ddpm_oracle as O
     cores = min(os.cpu_count() or 1, 64)
@@ -178,21 +179,21 @@ def cpu_baseline(cfg_name: str, batch: int):
     betas = O.create_noise_schedule(1e-6, 0.01, 1000, "linear")
     g = torch.Generator().manual_seed(1234)
     model = O.make_model(p, ocfg)
-    # size the bounded sample: probe 16 sequences, aim at <= ~25 s for 2 train steps (~3 fwd each) + 4 reverse steps
+    # size the bounded sample: probe 16 sequences, aim at <= ~75 s for 5 train steps (~3 fwd each) + 10 reverse steps
     xp = torch.randn(16, 32, 512, generator=g)
     with torch.no_grad():
         model(xp, torch.ones(16, 1, 1))
         t0 = time.perf_counter()
         model(xp, torch.ones(16, 1, 1))
         per_seq = (time.perf_counter() - t0) / 16
-    est = per_seq * batch * 10
-    b = batch if est <= 25 else max(16, int(batch * 25 / est) // 16 * 16)
+    est = per_seq * batch * 25
+    b = batch if est <= 75 else max(16, int(batch * 75 / est) // 16 * 16)
     log(f"cpu_baseline: {per_seq * 1e3:.1f} ms/sequence-forward on {cores} threads -> sample batch {b}")
     x0 = torch.clamp(0.25 * torch.randn(b, 32, 512, generator=g), -1, 1)
     labels = torch.randint(1, 1001, (b,), generator=g).numpy()
     eps = torch.randn(b, 32, 512, generator=g)
     st = O.AdamState()
-    n_train, n_rev = 2, 4                   # ~20 s of host work (BASELINE.md section 3 asks for 5 + 10: bounded here, and said so in the line)
+    n_train, n_rev = 5, 10
     t0 = time.perf_counter()
     for _ in range(n_train):
         p, _m, _g = O.train_step(p, ocfg, st, x0, betas, labels, eps, 1e-3, 1.0)
@@ -263,9 +264,14 @@ class Workload:
 
         # ---- sampler state (replicas: each rank walks its own B sequences).  With graph replay the batch is walked as two
         # concurrent half-batch chains on two streams, exactly as ncsn.diffusion_dynamics does (--sampler-chains 1: one chain).
-        self.nchains = nchains = 2 if (a.sampler_chains == 2 and not a.no_graph and B % 2 == 0 and (B // 2) * 32 % 256 == 0) else 1
+        # (N.sampler_chain_sizes: uneven splits in multiples of 8 sequences, e.g. 1000 -> 504 + 496; the bench never pads)
+        sizes, pad = N.sampler_chain_sizes(model, B, graphed=(a.sampler_chains == 2 and not a.no_graph))
+        if pad:
+            sizes = [B]
+        self.sizes = sizes
+        self.nchains = nchains = len(sizes)
         engines = model.chain_engines(2) if nchains == 2 else [model.engine]
-        hB = B // nchains
+        offs = self.offs = [0] + [sum(sizes[:i + 1]) for i in range(len(sizes) - 1)]
         self.x = x = torch.empty(B, 32, 512, device=dev)
         self.chains = []
         nk_d = None
@@ -279,16 +285,17 @@ class Workload:
                 k, _, v = kv.partition("=")
                 eng.set_option(k, int(v))
             eng.set_schedule(betas, with_sampler=True)
+            hB = sizes[c]
             eng.bind(hB, training=False)
             eng.prepare_sampler()
-            xc = x[c * hB:(c + 1) * hB]
-            eng.init_state(xc, 4321, rank * B + c * hB)
+            xc = x[offs[c]:offs[c] + hB]
+            eng.init_state(xc, 4321, rank * B + offs[c])
             ch = dict(eng=eng, x=xc, t_ptr=torch.tensor([999], dtype=torch.int32, device=dev),
                       metrics=torch.zeros(1000, hB, 3, device=dev), coll=torch.zeros(41, hB, 32, 512, device=dev),
                       graph=None, stream=chain_streams(torch, dev, nchains)[c] if nchains > 1 else None)
             io = lib.SampleIO()
             io.x, io.t_ptr = xc.data_ptr(), ch["t_ptr"].data_ptr()
-            io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B + c * hB
+            io.seed_lo, io.seed_hi, io.sample_offset = 7, 0, rank * B + offs[c]
             io.metrics_partial, io.collection, io.slot_table = ch["metrics"].data_ptr(), ch["coll"].data_ptr(), eng.slot_table.data_ptr()
             if nk_d is not None:
                 io.tf_noise_keys, io.tf_n_total, io.tf_t0 = nk_d.data_ptr(), world * B * 32 * 512, 999
@@ -316,11 +323,10 @@ class Workload:
         torch = self.torch
         import smd_amd.lib as lib
         self.restarts = getattr(self, "restarts", 0) + 1
-        hB = self.B // self.nchains
         for c, ch in enumerate(self.chains):   # the engine's own kernels on the chain's stream (no framework fill on the replay stream)
             st = ch["stream"] if ch["stream"] is not None else torch.cuda.current_stream()
             with torch.cuda.stream(st):
-                ch["eng"].init_state(ch["x"], 4321 + self.restarts, self.rank * self.B + c * hB)
+                ch["eng"].init_state(ch["x"], 4321 + self.restarts, self.rank * self.B + self.offs[c])
             lib.check(lib.get_lib().smd_set_timestep(ch["t_ptr"].data_ptr(), 999, st.cuda_stream))
         self.walked = 0
         if self.unroll and self.chains[0]["graph"] is not None:       # the pipeline's prologue: chain 0's first stem
@@ -415,20 +421,24 @@ class Workload:
     def final_loss(self) -> float:
         return float(self.opt.engine.loss_per_sample().mean())
 
-    def sampler_walk(self):
-        """One real 1000-step ``ncsn.sample`` call on B sequences (twice: the first call also pays the allocations)."""
+    def sampler_walk(self, num_samples=None):
+        """One real 1000-step ``ncsn.sample`` call on ``num_samples`` (default B) sequences (twice: the first call also pays the
+        allocations).  Returns (wall times, the arrangement ncsn.diffusion_dynamics chose)."""
         torch, N = self.torch, self.N
+        n = self.B if num_samples is None else int(num_samples)
         out = []
         for i in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            gen, coll, _m = N.sample(self.model, self.betas, N.make_key(11 + i, self.a.rng_impl), (32, 512), num_samples=self.B,
-                                     sampling="ddpm", sample_offset=self.rank * self.B)
+            gen, coll, _m = N.sample(self.model, self.betas, N.make_key(11 + i, self.a.rng_impl), (32, 512), num_samples=n,
+                                     sampling="ddpm", sample_offset=self.rank * n)
             torch.cuda.synchronize()
             out.append(time.perf_counter() - t0)
-            assert bool(torch.isfinite(gen).all()) and tuple(coll.shape) == (41, self.B, 32, 512)
+            assert bool(torch.isfinite(gen).all()) and tuple(coll.shape) == (41, n, 32, 512)
             del gen, coll
-        return out
+        arr = dict(getattr(self.model, "sampler_arrangement", {}))
+        self.model.drop_sampler_cache()
+        return out, arr
 
 
 def run_blocks(w: Workload, a, dist, do_train, do_sample, steps, warmup, repeats):
@@ -595,14 +605,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(dev))
 
     import smd_amd.lib as lib
-    from smd_amd.trainer import GradComm
+    from smd_amd.trainer import GradComm, assert_distinct_devices, gather_device_identities
 
     for kv in a.tuning:
         k, _, v = kv.partition("=")
-        lib.check(lib.get_lib().smd_set_tuning(k.encode(), int(v)))
+        lib.set_tuning(k, int(v))                  # (bumps lib.tuning_epoch(): cached sampler graphs are keyed on it)
     comm = (GradComm(buckets=a.dp_buckets, payload=a.dp_payload, algorithm=a.dp_algorithm, layer_buckets=bool(a.dp_layer_buckets),
                      measure_exposed=True, emulate_load=a.dp_dry_run)
             if world > 1 else None)
+    # which PHYSICAL device every rank sits on (UUID / PCI address), gathered over the job's own process group: N ranks must show
+    # N distinct devices or no line is printed (the SMD_BENCH_SHARE_DEVICE test hook is the one exception, and says so in `data`)
+    devices = gather_device_identities(dist if world > 1 else None)
+    assert_distinct_devices(devices, allow_shared=share)
     if a.dp_dry_run:
         return dp_dry_run(a, rank, world, dev, dist, comm)
     do_train, do_sample = a.mode in ("both", "train"), a.mode in ("both", "sample")
@@ -622,6 +636,7 @@ def main():
     sample_desc = (f"hipGraph replay, 2 half-batch chains pipelined (chain A: output stage + next stem, chain B: stem + output stage; "
                    f"{w.unroll} steps per graph, cross-chain event per replay)" if w.unroll
                    else "hipGraph replay, 2 free-running half-batch chains")
+    head_nchains = w.nchains
     fwd = FLOP_FWD_PER_SEQ[a.config] * a.batch
     head = summarise(blocks, a.steps, world, do_train, do_sample, fwd)
     loss = w.final_loss() if do_train else float("nan")
@@ -640,12 +655,19 @@ def main():
     walk = None
     extra = None
     if world == 1 and do_sample and not a.no_sampler_walk:
-        ws = w.sampler_walk()
+        ws, arr = w.sampler_walk()
         walk = {"sample_T1000_wall_s": round(ws[-1], 4), "first_call_wall_s": round(ws[0], 4),
-                "steps_per_sec": round(1000.0 / ws[-1], 1),
+                "steps_per_sec": round(1000.0 / ws[-1], 1), "arrangement": arr,
                 "what": f"ncsn.sample(sampling='ddpm', num_samples={a.batch}): init draw, FiLM tables for 1000 levels, operand refresh, "
                         "graph capture, 1000 reverse steps with collection + metrics, collate; second call of two"}
         log(f"real 1000-step sampler walk: {ws[-1]:.3f} s ({ws[0]:.3f} s first call)")
+        # the reference's own default sampling shape: sample_ncsn.py:54 sample_size = 1000, drawn as ONE batch (train_ncsn.py:540)
+        ws2, arr2 = w.sampler_walk(1000)
+        walk["num_samples_1000"] = {"sample_T1000_wall_s": round(ws2[-1], 4), "first_call_wall_s": round(ws2[0], 4),
+                                    "steps_per_sec": round(1000.0 / ws2[-1], 1),
+                                    "seq_steps_per_sec": round(1000.0 * 1000 / ws2[-1], 1), "arrangement": arr2}
+        walk["seq_steps_per_sec"] = round(1000.0 * a.batch / ws[-1], 1)
+        log(f"real 1000-step sampler walk of 1000 sequences: {ws2[-1]:.3f} s ({arr2.get('chain_sizes')})")
     if world == 1 and not a.no_extra_configs and a.mode == "both":
         extra = {}
         todo = [(c, d) for c in ("base", "large") for d in ("bf16", "fp8") if (c, d) != (a.config, a.dtype)]
@@ -661,6 +683,13 @@ def main():
             extra[name]["workload"] = (f"ddpm-{'mel' if d == 'bf16' else 'multi'}-32seq-512{'-large' if c == 'large' else ''}.cfg network, "
                                        f"batch={a.batch}, {d}")
             log(f"extra config {name}: {s['value']} denoising-steps/s")
+            if c == "large" and not a.no_sampler_walk:
+                # BASELINE config 4's own workload: a 1000-step reverse walk of the large net, B sequences per GPU
+                wl, arr = we.sampler_walk()
+                extra[name]["sampler_walk"] = {"sample_T1000_wall_s": round(wl[-1], 4), "first_call_wall_s": round(wl[0], 4),
+                                               "steps_per_sec": round(1000.0 / wl[-1], 1),
+                                               "seq_steps_per_sec": round(1000.0 * a.batch / wl[-1], 1), "arrangement": arr}
+                log(f"extra config {name}: 1000-step walk {wl[-1]:.3f} s")
             del we
             torch.cuda.empty_cache()
         w = None
@@ -674,7 +703,7 @@ def main():
         n_eval = (a.steps if do_train else 0) + (a.steps if do_sample else 0)
         total = head["t_train"] + head["t_sample"]
         B = a.batch
-        nch = 2 if (a.sampler_chains == 2 and not a.no_graph and B % 2 == 0 and (B // 2) * 32 % 256 == 0) else 1
+        nch = head_nchains
         out = {
             "metric": "denoising-steps/sec (train+sample), ddpm-mel-32seq-512",
             "value": head["value"], "unit": "denoising-steps/sec",
@@ -685,7 +714,8 @@ def main():
             "config": {"workload": f"ddpm-mel-32seq-512{'-large' if a.config == 'large' else ''}.cfg, batch={B}/GPU synthetic "
                                    f"(32,512) latents, random-init weights; step = 1 train_step + 1 reverse step",
                        "global_batch": B * world, "seq_len": 32, "parallelism": f"dp{world}", "mode": a.mode,
-                       **({"dp": {**comm.describe(), "collectives_per_step": dp_stats.get("collectives_per_step"),
+                       "devices": devices,
+                       **({"dp": {**comm.describe(), "devices": devices, "distinct_devices": len(set(devices)), "collectives_per_step": dp_stats.get("collectives_per_step"),
                                   "exposed_comm_us": dp_stats.get("exposed_comm_us"),
                                   "what": "exposed_comm_us = mean stall of the compute stream at GradComm.wait() per train step (HIP events)"}}
                           if world > 1 else {}),

@@ -207,6 +207,7 @@ class SmdEngine {
                 int ld_dx, const bf16_t* aux, int ld_aux, int aux_mode, hipStream_t st, bool allow_side = false);
   int wgrad(const DenseP& p, const bf16_t* X, int ldx, const bf16_t* dY, int ldy, int M, bool allow_side, hipStream_t st);
   int join_side(hipStream_t st);
+  int finish_backward(hipStream_t st, bool stem_ran);
   int ln_bwd(LnBwdArgs& b, hipStream_t st);
   int flush_ln_reduce(hipStream_t st);
   int flush_grouped_wgrads(hipStream_t st, bool on_caller_stream = false);

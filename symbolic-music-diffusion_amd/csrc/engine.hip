@@ -1107,13 +1107,19 @@ int SmdEngine::loss_backward(const float* x0, const int* labels, const float* ep
     RC(flush_ln_reduce(st));                       // one launch for every pending LayerNorm dgamma/dbeta
     RC(flush_grouped_wgrads(st, tail_on_main != 0));
   }
-  RC(join_side(st));         // every gradient is complete on `st` when this returns (stage 1: the output stage)
+  return finish_backward(st, stage == 0 || stage == 2);
+}
+
+// The tail both backward entry points share: join the side stream (every gradient is complete on `st` when this returns; after a
+// stage-1 call: the output stage's) and, with dp_layer_events on and the stem backward in this call, leave the event that
+// smd_engine_wait_grad_bucket falls back to for a bucket without a per-layer event.
+int SmdEngine::finish_backward(hipStream_t st, bool stem_ran) {
   stem_done_valid_ = false;
-  if (dp_layer_events && (stage == 0 || stage == 2)) {
-    // what smd_engine_wait_grad_bucket falls back to for a bucket without a per-layer event
-    if (!stem_done_ev_) SMD_ARG_CHECK(hipEventCreateWithFlags(&stem_done_ev_, hipEventDisableTiming) == hipSuccess, "loss_backward: cannot create an event");
+  RC(join_side(st));
+  if (dp_layer_events && stem_ran) {
+    if (!stem_done_ev_) SMD_ARG_CHECK(hipEventCreateWithFlags(&stem_done_ev_, hipEventDisableTiming) == hipSuccess, "backward: cannot create an event");
     hipError_t e = hipEventRecord(stem_done_ev_, st);
-    if (e != hipSuccess) { smd_set_error("loss_backward: event: %s", hipGetErrorString(e)); return (int)e; }
+    if (e != hipSuccess) { smd_set_error("backward: event: %s", hipGetErrorString(e)); return (int)e; }
     stem_done_valid_ = true;
   }
   return 0;
@@ -1139,6 +1145,7 @@ int SmdEngine::backward_from(const float* dpred, int stage, hipStream_t st) {
   SMD_ARG_CHECK(training_ && grads_ && batch_ > 0, "backward_from: bind a training workspace and the optimiser state first");
   SMD_ARG_CHECK(stage >= 0 && stage <= 2, "backward_from: stage=%d", stage);
   SMD_ARG_CHECK(stage == 2 || dpred, "backward_from: null gradient");
+  stem_done_valid_ = false;          // the event of an EARLIER backward orders nothing about this one (wait_grad_bucket's fallback)
   if (stage != 2) {
     const bool need_memset = grad_memset == 1 || (grad_memset == 2 && !(tr_path == 1));
     if (need_memset) {
@@ -1156,7 +1163,7 @@ int SmdEngine::backward_from(const float* dpred, int stage, hipStream_t st) {
     RC(flush_ln_reduce(st));
     RC(flush_grouped_wgrads(st, tail_on_main != 0));
   }
-  return join_side(st);
+  return finish_backward(st, stage != 1);
 }
 
 int SmdEngine::optimizer_step(const TrainHyper& h, hipStream_t st) {

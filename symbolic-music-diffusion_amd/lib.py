@@ -199,7 +199,12 @@ def get_lib() -> C.CDLL:
     if lib.smd_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsmd_hip.so ABI {lib.smd_abi_version()} != {ABI_VERSION}; rebuild")
     have, want = lib.smd_build_id().decode(), _build.source_id()
-    if have != want and os.environ.get("SMD_ALLOW_STALE_LIB") != "1":
+    if have != want and os.environ.get("SMD_LIB_SUFFIX"):
+        # an experiment library (tools/*.sh build these with their own SMD_EXTRA_DEFS / SMD_SLP, which feed the id): never rebuilt
+        # implicitly and not expected to match the loading process's flags -- say so and go on
+        import warnings
+        warnings.warn(f"{path}: experiment library with build id {have} (this environment's tree id is {want})")
+    elif have != want and os.environ.get("SMD_ALLOW_STALE_LIB") != "1":
         raise RuntimeError(f"{path} was built from other sources (build id {have}, this tree is {want}) and could not be "
                            "rebuilt here: run `python -m smd_amd.build` where hipcc exists (SMD_ALLOW_STALE_LIB=1 overrides)")
     _LIB = lib

@@ -13,6 +13,8 @@ sequences calls and reproduces the reference's output layouts and quirks.
 from __future__ import annotations
 
 import ctypes as C
+import logging
+import math
 import os
 import time
 from dataclasses import dataclass
@@ -28,6 +30,7 @@ from .engine import ARCH_IDS, Engine, NetConfig
 from .jax_random import ThreefryKey
 
 COLLECTION_STEPS = _sched.COLLECTION_STEPS
+_log = logging.getLogger("smd_amd.sampler")
 
 
 # ------------------------------------------------------------------ rng keys
@@ -582,14 +585,30 @@ def collate_sampling_metrics(ld_metrics):
     return out
 
 
-def _sampler_chains(model: "Model", B: int, graphed: bool) -> int:
-    """2 when the graph-replayed walk of B sequences is split into two concurrent chains (SMD_SAMPLER_CHAINS=1 turns it off)."""
-    import os
-    if not graphed or os.environ.get("SMD_SAMPLER_CHAINS", "2") != "2":
-        return 1
+def sampler_chain_sizes(model: "Model", B: int, graphed: bool, allow_pad: bool = True) -> Tuple[List[int], int]:
+    """How the graph-replayed walk of B sequences is arranged: ``(sizes, pad)``.  Two concurrent chains (SMD_SAMPLER_CHAINS=1
+    turns it off) whenever B >= 128: the batch is split UNEVENLY in multiples of the row granule of the 256-row GEMM tiles
+    (8 sequences of 32 tokens), e.g. the reference's default ``sample_size = 1000`` (sample_ncsn.py:54) walks as 504 + 496; a batch
+    that is not a multiple of the granule is padded with ``pad`` <= 7 throw-away sequences (samples are independent and every draw
+    is keyed by the global sample index, so the padding changes no result; it is sliced off before anything is returned).
+    ``allow_pad=False`` (jax.random streams: their counter layout is a function of the true array size): such a batch walks as one chain."""
     eng = model.engine
-    rows = (B // 2) * eng.S
-    return 2 if (B % 2 == 0 and B >= 128 and rows % 256 == 0 and eng.cfg.mlp_dims % 256 == 0) else 1
+    if not graphed or os.environ.get("SMD_SAMPLER_CHAINS", "2") != "2" or B < 128 or eng.cfg.mlp_dims % 256:
+        return [B], 0
+    gran = 256 // math.gcd(256, eng.S)                  # sequences per 256 token rows: 8 for S = 32, 256 for DenseDDPM
+    pad = (-B) % gran
+    if pad and (not allow_pad or gran > 8):
+        return [B], 0
+    Bp = B + pad
+    h0 = (Bp // 2 + gran - 1) // gran * gran
+    if Bp - h0 < gran:
+        return [B], 0
+    return [h0, Bp - h0], pad
+
+
+def _sampler_chains(model: "Model", B: int, graphed: bool) -> int:
+    """Number of concurrent chains of the graph-replayed walk of B sequences (see sampler_chain_sizes)."""
+    return len(sampler_chain_sizes(model, B, graphed)[0])
 
 
 def _sampler_pipeline_unroll() -> int:
@@ -656,13 +675,23 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     # iteration k, stem of iteration k + 1) and chain B as (stem, output stage) of iteration k, `unroll` iterations per graph,
     # and every replay of one chain waits for the previous replay of the other: the phase is re-locked every `unroll`
     # iterations and the two halves always complement each other (include/smd_hip.h smd_engine_sample_step_part).
-    nchains = _sampler_chains(model, B, graphed)
+    # The split is uneven in multiples of 8 sequences (B = 1000, the reference's default sample_size: 504 + 496) and a batch that
+    # is not a multiple of 8 is padded with throw-away sequences, so every B >= 128 takes this path (sampler_chain_sizes).
+    sizes, pad = sampler_chain_sizes(model, B, graphed, allow_pad=not jax_mode)
+    nchains = len(sizes)
+    offs = [0] + list(np.cumsum(sizes)[:-1])
     unroll = _sampler_pipeline_unroll() if nchains == 2 else 0
     engines = model.chain_engines(nchains) if nchains > 1 else [eng]
-    h = B // nchains
+    model.sampler_arrangement = dict(batch=B, chains=nchains, chain_sizes=list(sizes), padded=pad, graphed=bool(graphed),
+                                     pipelined_unroll=unroll, rng="threefry" if jax_mode else ("explicit" if explicit else "philox"))
+    _log.info("diffusion_dynamics: B=%d as %d chain(s) %s (+%d padding), %s", B, nchains, list(sizes), pad,
+              f"pipelined, {unroll} steps per graph" if unroll else ("graph replay" if graphed else "eager launches"))
+    if pad:
+        zp = lambda t: None if t is None else torch.cat([t, torch.zeros((pad, *t.shape[1:]), dtype=t.dtype, device=dev)])
+        x, start, inf_s, inf_m = zp(x), zp(start), zp(inf_s), zp(inf_m)
     for c, e in enumerate(engines):
         _ensure_schedule(e, betas, with_sampler=True)
-        e.bind(h, training=False)
+        e.bind(sizes[c], training=False)
     # A captured step is valid for LATER runs too as long as every pointer it holds is: the state / collection / metrics
     # buffers, the device-resident timestep, Philox key (smd_sample_io.key_ptr) and jax.random key tables are kept with the
     # graphs (one set per model) and refilled per run; the weights are read through the shared operand pack.  A second
@@ -670,13 +699,15 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
     # ... and as long as nothing the captured kernels bake in has changed under it: every handle counts its binds, schedule
     # changes and option changes (Engine.generation); process-wide tuning knobs are part of the key through lib.tuning_epoch()
     sig = tuple((id(e), e.generation) for e in engines) + (_lib.tuning_epoch(),)
-    ckey = (B, nchains, unroll, bool(infill), jax_mode, nT, t_hi, len(steps), int(sample_offset), int(n_glob), tuple(init.shape[1:]))
+    ckey = (B, tuple(sizes), pad, nchains, unroll, bool(infill), jax_mode, nT, t_hi, len(steps), int(sample_offset), int(n_glob), tuple(init.shape[1:]))
     cache = model.__dict__.setdefault("_sampler_graphs", {})
     entry = cache.get("entry") if graphed else None
     reuse = entry is not None and entry["key"] == ckey and entry["sig"] == sig
     if reuse:
         x = entry["x"]
-        x.copy_(init)
+        x[:B].copy_(init)
+        if pad:
+            x[B:].zero_()
         chains = entry["chains"]
         if jax_mode:
             entry["nk_d"].copy_(nk_d)
@@ -695,7 +726,8 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
         if c == 0:
             e.refresh_weights()    # the fp32 master may have been trained since the last call (the operand pack is shared)
         e.prepare_sampler()        # FiLM scale/shift tables for all T noise levels (3 small GEMMs per block)
-        lo, hi = c * h, (c + 1) * h
+        h = sizes[c]
+        lo, hi = int(offs[c]), int(offs[c]) + h
         if reuse:
             ch = chains[c]
             ch["coll"].zero_()
@@ -809,9 +841,9 @@ def diffusion_dynamics(rng: PRNGKey, model: Model, betas, init, epsilon=None, T=
             chains[0]["eng"].sample_step(chains[0]["io"])
 
     if graphed:
-        x = x.clone()                      # the persistent state buffer belongs to the cached graphs
-    collection = (chains[0]["coll"].clone() if graphed else chains[0]["coll"]) if nchains == 1 else torch.cat([ch["coll"] for ch in chains], dim=1)
-    metrics_partial = chains[0]["metrics"] if nchains == 1 else torch.cat([ch["metrics"] for ch in chains], dim=1)
+        x = x[:B].clone()                  # the persistent state buffer belongs to the cached graphs
+    collection = (chains[0]["coll"].clone() if graphed else chains[0]["coll"]) if nchains == 1 else torch.cat([ch["coll"] for ch in chains], dim=1)[:, :B]
+    metrics_partial = chains[0]["metrics"] if nchains == 1 else torch.cat([ch["metrics"] for ch in chains], dim=1)[:, :B]
     # ld_metrics rows (grad_norm, step_norm, alpha_prod, noise_norm), one column per iteration (:380-405)
     denom = float(B) if eng.S == 1 else float(B * eng.C)
     per_t = metrics_partial.sum(dim=1) / denom                                      # (T, 3) indexed by t

@@ -79,8 +79,10 @@ def _(x, noise_level, params, engine):
 
 @torch.library.custom_op("smd_amd::eps_backward", mutates_args=())
 def eps_backward(dpred: torch.Tensor, engine: int, generation: int) -> torch.Tensor:
-    """The engine's backward pass from d objective / d eps_hat; returns the flat parameter gradient (a copy of the engine's
-    gradient buffer, which every backward pass overwrites)."""
+    """The engine's backward pass from d objective / d eps_hat; returns the flat parameter gradient: a fresh tensor object that
+    ALIASES the engine's gradient buffer (no 100 MB copy per step).  The buffer is overwritten by the handle's next backward
+    pass -- one outstanding forward / backward pair per handle, as eps_forward_train already requires; autograd either adopts
+    the alias as ``params.grad`` (trainer._train_step_generic then skips its copy-back) or clones it while accumulating."""
     _need_gpu(dpred)
     eng = _ENGINES.get(engine)
     if eng is None:
@@ -89,7 +91,7 @@ def eps_backward(dpred: torch.Tensor, engine: int, generation: int) -> torch.Ten
         raise RuntimeError("smd_amd::eps_backward: the engine has run another training forward pass since this one (one "
                            "workspace per handle: call backward() before the next model(x, cond), or use a second handle)")
     eng.backward_from(dpred)
-    return eng.grads.clone()
+    return eng.grads.detach()
 
 
 @eps_backward.register_fake

@@ -7,8 +7,9 @@ data-parallel training, one process per GPU, gradients summed with RCCL all-redu
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -170,7 +171,9 @@ def _train_step_generic(objective, batch, optimizer: Optimizer, sigmas, rng, lea
     if dm.params.grad is None:
         raise ValueError("train_step: the objective did not reach the model's parameters")
     # the engine's gradient buffer holds the last backward pass; autograd's accumulated leaf gradient is the authoritative one
-    eng.grads.copy_(dm.params.grad)
+    # (it may BE the engine's buffer: eps_backward returns an alias that autograd can adopt)
+    if dm.params.grad.data_ptr() != eng.grads.data_ptr():
+        eng.grads.copy_(dm.params.grad)
     dm.params.grad = None
     world = 1
     if comm is not None:
@@ -358,6 +361,41 @@ class GradComm:
     def broadcast_params(self, flat: torch.Tensor, src: int = 0) -> None:
         if self.world_size > 1:
             self.dist.broadcast(flat, src=src, group=self.group)
+
+
+def device_identity(index: Optional[int] = None) -> str:
+    """A string that names the PHYSICAL device behind ``cuda:index`` of this process: its UUID when the runtime reports one,
+    else PCI domain:bus:device, else the ordinal -- what the bench line lists per rank so that N ranks can be seen to sit on
+    N distinct GPUs (a CPU-only process reports ``cpu:<hostname>:<pid>``)."""
+    if not torch.cuda.is_available():
+        import socket
+        return f"cpu:{socket.gethostname()}:{os.getpid()}"
+    i = torch.cuda.current_device() if index is None else int(index)
+    pr = torch.cuda.get_device_properties(i)
+    uuid = getattr(pr, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return f"uuid:{uuid}"
+    bus = getattr(pr, "pci_bus_id", None)
+    if bus is not None:
+        return f"pci:{getattr(pr, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+    return f"ordinal:{i}"
+
+
+def gather_device_identities(dist=None, group=None, mine: Optional[str] = None) -> List[str]:
+    """Every rank's ``device_identity()`` in rank order (all_gather_object over the job's process group; one entry without
+    torch.distributed).  ``assert_distinct_devices`` is the check on top of it."""
+    mine = device_identity() if mine is None else mine
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [mine]
+    out: List[Optional[str]] = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, mine, group=group)
+    return [str(o) for o in out]
+
+
+def assert_distinct_devices(ids: List[str], allow_shared: bool = False) -> None:
+    """A data-parallel job whose ranks share a GPU measures nothing: refuse (``allow_shared``: the one-GPU test hook)."""
+    if len(set(ids)) != len(ids) and not allow_shared:
+        raise RuntimeError(f"data-parallel ranks share a device: {ids}")
 
 
 def shard_bounds(num_items: int, world_size: int, rank: int):

@@ -970,7 +970,7 @@ def test_pipelined_two_chain_walk_is_the_free_running_walk_bitwise(arch, unroll,
         again = N.diffusion_dynamics(key, model, BETAS, init, t_stop=t_stop)      # through the cached graphs
         for u, v, w_ in zip(ref, got, again):
             assert torch.equal(u, v) and torch.equal(u, w_)
-        assert model._sampler_graphs["entry"]["key"][2] == unroll
+        assert model._sampler_graphs["entry"]["key"][4] == unroll
 
 
 @pytest.mark.parametrize("arch,C,K,dtype", [("TransformerDDPM", 512, 2, "bf16"), ("TransformerDDPM", 146, 3, "bf16"), ("DenseDDPM", 512, 2, "bf16"),
