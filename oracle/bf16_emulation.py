@@ -112,11 +112,22 @@ def _film(P, t, name, film_channels, mlp_dims, sequence):
     return ss[..., :mlp_dims], ss[..., mlp_dims:]
 
 
+_RES_DENSE = None      # fp8 mode (oracle/e4m3_emulation.py): callable(a_unrounded, W_bf16, bias) -> a W + b on e4m3 operands
+
+
+def _res_dense(P, act, name):
+    """one Dense of a DenseResBlock on the FiLM-LayerNorm output `act` (un-rounded): bf16 operands by default; in fp8 mode the
+    LayerNorm kernel writes the row as e4m3 + an E8M0 row scale (and a bf16 copy for the weight gradient), see e4m3_emulation.py"""
+    if _RES_DENSE is not None:
+        return _RES_DENSE(H(act), P.w(name), P.b(name))
+    return H(rb(act)) @ P.w(name) + P.b(name)
+
+
 def _res_block(P, y, name, scale, shift):
-    a = H(rb(O.swish(scale * P.ln(y, name + ".ln1") + shift)))   # dgrad output of fc1 -> bf16
-    o1 = H(rb(a @ P.w(name + ".fc1") + P.b(name + ".fc1")))      # d o1 (LayerNorm 2 backward output) -> bf16
-    a = H(rb(O.swish(scale * P.ln(o1, name + ".ln2") + shift)))  # dgrad output of fc2 -> bf16
-    return H(rb(a @ P.w(name + ".fc2") + P.b(name + ".fc2") + y))  # trunk gradient dy -> bf16
+    a = O.swish(scale * P.ln(y, name + ".ln1") + shift)          # (H: dgrad output of fc1 -> bf16)
+    o1 = H(rb(_res_dense(P, a, name + ".fc1")))                  # d o1 (LayerNorm 2 backward output) -> bf16
+    a = O.swish(scale * P.ln(o1, name + ".ln2") + shift)         # (H: dgrad output of fc2 -> bf16)
+    return H(rb(_res_dense(P, a, name + ".fc2") + y))            # trunk gradient dy -> bf16
 
 
 def _attention(P, a1, name, num_heads):

@@ -374,3 +374,34 @@ def test_score_matching_and_langevin_closed_forms():
     beta = (1 - (1 - 5e-4 / 0.05 ** 2) ** 2) ** 0.5
     assert torch.allclose(st, init + beta * (0.1 + 0.05), rtol=1e-5) and met.shape == (4, 3, 1)
     assert float(met[3, 2, 0]) == pytest.approx(1e-5)                                     # noise norm of the last level: 0
+
+
+def test_e4m3_emulation_quantiser_known_answers():
+    """oracle/e4m3_emulation.py restates the ENGINE's e4m3 storage (csrc/smd_common.h e4m3_row_exponent / pack4_e4m3): the OCP
+    e4m3 grid (3 mantissa bits, max 448, subnormal step 2^-9), round-to-nearest-even, saturation, and the row-exponent rule."""
+    import e4m3_emulation as F8
+    r = F8.round_e4m3(torch.tensor([0.0, 1.0, 1.0625, 1.1875, 17.0, 18.0, 19.0, 448.0, 0.001953125, 0.0009765625, -0.40625], dtype=torch.float64))
+    # ties to even: 1.0625 -> 1.0 (mantissa 000 vs 001), 1.1875 -> 1.25 (between 1.125 and 1.25: even is 1.25); 17 -> 16, 19 -> 20 (step 2), 18 stays
+    assert r.tolist() == [0.0, 1.0, 1.0, 1.25, 16.0, 18.0, 20.0, 448.0, 0.001953125, 0.0, -0.40625]
+    e = F8.e4m3_row_exponent(torch.tensor([1.0, 1.75, 1.7500001, 3.9, 448.0, 0.0, 2.0 ** -140]))
+    assert e.tolist() == [-8, -8, -7, -6, 0, 0, -126]
+    # a row is scaled so that its maximum lands in (224, 448]: never saturated, never more than one binade of head-room wasted
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 256, generator=g, dtype=torch.float64) * torch.logspace(-6, 6, 64, dtype=torch.float64)[:, None]
+    q = F8.q8_rows(x)
+    amax = x.abs().amax(1)
+    s = 2.0 ** F8.e4m3_row_exponent(amax.float()).double()
+    assert bool(((amax / s) <= 448.0).all()) and bool(((amax / s) > 224.0 * 0.999).all())
+    assert float(((q - x).abs() / amax[:, None]).max()) <= 2.0 ** -4 + 1e-12          # half a step of the top binade (32 / 448 / 2 ... <= 1/16)
+    assert float((q - x).norm() / x.norm()) < 4e-2
+    # the Dense: forward on quantised operands, dgrad on quantised dY and the per-input-feature quantised kernel, wgrad on bf16 copies
+    import bf16_emulation as E
+    a = torch.randn(8, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    W = E._round(torch.randn(64, 32, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = torch.zeros(32, dtype=torch.float64, requires_grad=True)
+    out = F8.F8Dense.apply(a, W, b)
+    assert torch.equal(out.detach(), F8.q8_rows(a) @ F8.q8_rows(W.detach().t()).t())
+    dY = E._round(torch.randn(8, 32, generator=g, dtype=torch.float64))
+    out.backward(dY)
+    assert torch.equal(a.grad, F8.q8_rows(dY) @ F8.q8_rows(W.detach()).t())
+    assert torch.equal(W.grad, E._round(a.detach()).t() @ dY) and torch.equal(b.grad, dY.sum(0))

@@ -15,10 +15,22 @@ nst = len(wins)
 
 
 def short(n):
-    m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)(<[^()]*>)?\s*\(", n) or re.search(r"([A-Za-z_][A-Za-z0-9_]*_kernel)(<[^()]*>)?", n)
-    if not m:
-        return n[-60:]
-    return (m.group(1) + (m.group(2) or ""))[-70:]
+    n = n.strip()
+    if n.startswith("void "):
+        n = n[5:]
+    m = re.search(r"\d+([A-Za-z0-9_]+_kernel)", n) if n.startswith("_Z") else None
+    if m:
+        return m.group(1)
+    depth, out = 0, []
+    for ch in n:                       # up to the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out)[-72:]
 
 
 per = {}
