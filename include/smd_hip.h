@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SMD_ABI_VERSION 5   /* 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots; 4: one-sweep optimiser, "opt_overlap", smd_engine_join_update; 5: smd_build_id, smd_engine_sample_step_part, smd_engine_forward_train / backward_from; the lab hooks (tuning knobs, debug tensors, probes) moved to smd_hip_lab.h -- this header is the stable surface */
+#define SMD_ABI_VERSION 6   /* 6: smd_attn_block_bwd_ln (the attention backward with both LayerNorm backwards in the launch), "fused_attn_bwd" 2; 2: smd_ddpm_reverse_step takes T; hidden-split MLP, fp8, loss-side and Langevin entries; 3: smd_langevin_io table mode, debug snapshots; 4: one-sweep optimiser, "opt_overlap", smd_engine_join_update; 5: smd_build_id, smd_engine_sample_step_part, smd_engine_forward_train / backward_from; the lab hooks (tuning knobs, debug tensors, probes) moved to smd_hip_lab.h -- this header is the stable surface */
 
 typedef uint16_t smd_bf16;
 typedef struct smd_engine smd_engine;
@@ -74,7 +74,7 @@ int smd_engine_padded_channels(const smd_engine* e);
  *   "side_wgrad" 0/1     weight-gradient GEMMs (and the gradient memset, FiLM chains) on the engine's low-priority side
  *                        stream, joined inside smd_engine_loss_backward; the Python host turns it on for training handles
  *   "group_wgrad" 2, "pair_wgrad" 1, "film_side" 1, "film_side_fwd" 1, "tail_on_main" 1   launch grouping of those GEMMs
- *   "fused_encoder" 1, "fused_attn_bwd" 1, "mlp_hs" 1   fused encoder half-layers / hidden-split MLP (0: separate launches)
+ *   "fused_encoder" 1, "fused_attn_bwd" 2 (2: + both LayerNorm backwards in the launch, 1: attention only), "mlp_hs" 1   fused encoder half-layers / hidden-split MLP (0: separate launches)
  *   "resgrad_bf16" 1     DenseResBlock residual-gradient chain in bf16
  *   "trunk_bf16" 2       2048-wide residual stream in bf16 (2: inference + training, 1: inference only, 0: fp32)
  *   "fp8" 0/1            e4m3 DenseResBlock forward GEMMs (BASELINE config 5); "w8_dirty" 1: operand pack changed elsewhere
@@ -301,6 +301,16 @@ int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* g
  * from the saved qkv), da1 = dqkv Wqkv^T.  Wo [128 in][128 out], Wqkv [128 in][384 out]: bf16, out index contiguous. */
 int smd_attn_block_bwd(const smd_bf16* dh_mid, const smd_bf16* qkv, const smd_bf16* Wo, const smd_bf16* Wqkv,
                        smd_bf16* dqkv, smd_bf16* da1, int rows, int num_heads, void* stream);
+/* The backward of models/ncsn.py:159-164 from the MLP's input gradient to the layer's input gradient in ONE launch: LayerNorm-2
+ * backward on da2 given as four partial tiles (part_stride floats apart, summed (p0 + p1) + (p2 + p3)) + the residual gradient dh,
+ * the attention half-layer backward (smd_attn_block_bwd), LayerNorm-1 backward + residual.  dh [rows][128] fp32 is read and then
+ * overwritten IN PLACE with the gradient that leaves the layer; dh_mid_out / dh_out: its bf16 copies between the half-layers (the
+ * operand of out_proj's weight gradient) and at the exit; partial1 / partial2 [rows/32][2][128]: dgamma | dbeta sums per sample
+ * of LayerNorm 1 / 2 (reduce with smd_ln_bwd_reduce); da1 optional. */
+int smd_attn_block_bwd_ln(const smd_bf16* qkv, const smd_bf16* Wo, const smd_bf16* Wqkv, smd_bf16* dqkv, smd_bf16* da1,
+                          const float* h_mid, const float* da2_parts, int64_t part_stride, const float* gamma2, float* dh,
+                          smd_bf16* dh_mid_out, float* partial2, const float* h, const float* gamma1, smd_bf16* dh_out,
+                          float* partial1, int rows, int num_heads, void* stream);
 /* dW[Kd,N] = X[M,Kd]^T dY[M,N] and db[N] = colsum(dY) (weight + bias gradient of nn.Dense).
  * tr_path 1: zero_page = 128 zeroed bf16, slab = smd_gemm_tn_slab_elems() floats (split-K partials);
  * tr_path 0: scratch = (Kd+N)*roundup(M,64) bf16 for explicit transposes (+ slab for the bias). */

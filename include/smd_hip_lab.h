@@ -48,6 +48,7 @@ int smd_engine_debug_tensor(const smd_engine* e, const char* name, int index, co
  *               experiment build);
  * "gemm_nt_form": 0 (default) = the 128-column kernel picks its tile form from the shape; 1 .. 6 force <64,2>, <128,2>,
  *               <128,2,two K-groups>, <64,2,two K-groups>, <128,3>, <64,3,two K-groups> (tools/gemm_nt_forms_ab.py);
+ *               "gemm_nt_form_wk": the same forms for the wide-K, few-column shapes only (N <= 512, K >= 2048: out_proj);
  * further keys ("ln_bwd_wide", "ln_fwd_wide", "ln_bwd_narrow", "gemm_nt_deep", "gemm_nt_kg", "mlp_variant", ...) select
  * between equivalent kernels for A/B runs; unknown keys return < 0. */
 int smd_set_tuning(const char* key, int value);

@@ -82,7 +82,7 @@ int smd_engine_set_option(smd_engine* e, const char* key, int value) {
   SMD_ARG_CHECK(key, "set_option: null key");
   if (std::string(key) == "tr_path") { e->impl.tr_path = value ? 1 : 0; return 0; }
   if (std::string(key) == "side_wgrad") return e->impl.set_side_stream(value);
-  if (std::string(key) == "fused_attn_bwd") { e->impl.fused_attn_bwd = value ? 1 : 0; return 0; }
+  if (std::string(key) == "fused_attn_bwd") { e->impl.fused_attn_bwd = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
   if (std::string(key) == "resgrad_bf16") { e->impl.resgrad_bf16 = value ? 1 : 0; return 0; }
   if (std::string(key) == "film_side") { e->impl.film_side = value; return 0; }
   if (std::string(key) == "pair_wgrad") { e->impl.pair_wgrad = value ? 1 : 0; return 0; }
@@ -279,6 +279,16 @@ int smd_attn_block_fwd(const float* h_in, float* h_out, int rows, const float* g
 int smd_attn_block_bwd(const smd_bf16* dh_mid, const smd_bf16* qkv, const smd_bf16* Wo, const smd_bf16* Wqkv, smd_bf16* dqkv,
                        smd_bf16* da1, int rows, int num_heads, void* stream) {
   return launch_attn_block_bwd(B(dh_mid), B(qkv), B(Wo), B(Wqkv), B(dqkv), B(da1), rows, num_heads, S(stream));
+}
+int smd_attn_block_bwd_ln(const smd_bf16* qkv, const smd_bf16* Wo, const smd_bf16* Wqkv, smd_bf16* dqkv, smd_bf16* da1,
+                          const float* h_mid, const float* da2_parts, int64_t part_stride, const float* gamma2, float* dh,
+                          smd_bf16* dh_mid_out, float* partial2, const float* h, const float* gamma1, smd_bf16* dh_out,
+                          float* partial1, int rows, int num_heads, void* stream) {
+  AttnBwdLnArgs a;
+  a.qkv = B(qkv); a.Wo = B(Wo); a.Wqkv = B(Wqkv); a.dqkv = B(dqkv); a.da1 = B(da1);
+  a.h_mid = h_mid; a.da2_parts = da2_parts; a.part_stride = (size_t)part_stride; a.gamma2 = gamma2; a.dh = dh;
+  a.dh_mid_out = B(dh_mid_out); a.partial2 = partial2; a.h = h; a.gamma1 = gamma1; a.dh_out = B(dh_out); a.partial1 = partial1;
+  return launch_attn_block_bwd_ln(a, rows, num_heads, S(stream));
 }
 int smd_gemm_bf16_tn(const smd_bf16* X, int ldx, const smd_bf16* dY, int ldy, int M, int Kd, int N, float* out, int ldo,
                      float* bias_out, const smd_bf16* zero_page, float* slab, int64_t slab_elems, smd_bf16* scratch,

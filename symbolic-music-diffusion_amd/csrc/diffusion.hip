@@ -104,6 +104,65 @@ __global__ __launch_bounds__(256) void q_sample_kernel(QSampleArgs a) {
   if (g == 0) a.s_out[b] = a.dsm ? sb : sa;
 }
 
+// The same for C % 4 == 0 and Cp % 4 == 0 (a group of four never straddles a row): QPT groups per thread with all x0 loads issued
+// first, ONE 8-byte bf16 store and one 16-byte eps store per group, the row index from a float reciprocal (S C < 2^22) -- and the
+// label draw / alpha lookup / square roots once per QPT groups.  Same Philox counters as q_sample_kernel: the same draws.
+template <int QPT>
+__global__ __launch_bounds__(256) void q_sample_quads_kernel(QSampleArgs a) {
+  const int SC = a.S * a.C, nq = SC >> 2;
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * (256 * QPT) + threadIdx.x;
+  const size_t sbase = (size_t)b * SC;
+  float4 x0[QPT], ein[QPT];
+#pragma unroll
+  for (int k = 0; k < QPT; ++k) {
+    const int q = q0 + k * 256;
+    if (q < nq) {
+      x0[k] = *reinterpret_cast<const float4*>(a.x0 + sbase + (size_t)q * 4);
+      if (a.eps_in) ein[k] = *reinterpret_cast<const float4*>(a.eps_in + sbase + (size_t)q * 4);
+    }
+  }
+  const uint32_t bglob = (uint32_t)b + a.sample_offset;
+  const uint32_t step = a.step_ptr ? *a.step_ptr : 0u;
+  int label;
+  uint4 r = make_uint4(0u, 0u, 0u, 0u);
+  if (a.labels) {
+    label = min(max(a.labels[b], 0), a.T);
+    if (label == 0 && !a.alpha_in && !a.dsm) r = philox4x32_10(make_uint4(0u, bglob, SMD_STREAM_LABEL, step), a.key.seed_lo, a.key.seed_hi);
+  } else {
+    r = philox4x32_10(make_uint4(0u, bglob, SMD_STREAM_LABEL, step), a.key.seed_lo, a.key.seed_hi);
+    label = a.label_min + (int)(r.x % (uint32_t)a.T);                 // utils/losses.py:272-275
+  }
+  float alpha;
+  if (a.dsm) alpha = 0.f;
+  else if (a.alpha_in) alpha = a.alpha_in[b];
+  else if (label > 0) alpha = a.alphas_prod_ext[label - 1];           // jax-0.2.8 uniform(minval > maxval) = minval
+  else {
+    const float lo = a.alphas_prod_ext[a.T];
+    const float u = __uint_as_float((r.y >> 9) | 0x3F800000u) - 1.0f;
+    alpha = fmaxf(lo, u * (1.0f - lo) + lo);
+  }
+  const float sa = a.dsm ? 1.0f : sqrtf(alpha), sb = a.dsm ? a.alpha_in[b] : sqrtf(1.0f - alpha);
+  const float invC = 1.0f / (float)a.C;
+#pragma unroll
+  for (int k = 0; k < QPT; ++k) {
+    const int q = q0 + k * 256;
+    if (q >= nq) continue;
+    const float4 eps = a.eps_in ? ein[k] : philox_normal4((uint32_t)q, bglob, SMD_STREAM_EPS, step, a.key.seed_lo, a.key.seed_hi);
+    const int e = q * 4;
+    int srow = (int)((float)e * invC);
+    srow -= (srow * a.C > e);
+    srow += ((srow + 1) * a.C <= e);
+    const int c = e - srow * a.C;
+    bf16x4_t t;
+    t[0] = f2bf(sa * x0[k].x + sb * eps.x); t[1] = f2bf(sa * x0[k].y + sb * eps.y);
+    t[2] = f2bf(sa * x0[k].z + sb * eps.z); t[3] = f2bf(sa * x0[k].w + sb * eps.w);
+    *reinterpret_cast<bf16x4_t*>(a.xt_bf16 + ((size_t)b * a.S + srow) * a.Cp + c) = t;
+    *reinterpret_cast<float4*>(a.eps_out + sbase + (size_t)e) = eps;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.s_out[b] = a.dsm ? sb : sa;
+}
+
 template <int VEC> struct VecT;
 template <> struct VecT<4> { typedef float4 type; };
 template <> struct VecT<1> { typedef float type; };
@@ -469,6 +528,13 @@ int launch_q_sample(const QSampleArgs& a, hipStream_t st) {
   SMD_ARG_CHECK(a.label_min == 0 || a.label_min == 1, "q_sample: label_min=%d", a.label_min);
   SMD_ARG_CHECK(!a.dsm || a.alpha_in, "q_sample: the score-matching form needs the per-sample used_sigmas");
   const int groups = (a.S * a.C + 3) / 4;
+  if (a.C % 4 == 0 && a.Cp % 4 == 0 && a.S * a.C < (1 << 22)) {
+    // four groups per thread when that still leaves >= 4 workgroups per CU, else one
+    if ((long)a.B * ((groups + 1023) / 1024) >= 1024) hipLaunchKernelGGL(q_sample_quads_kernel<4>, dim3((groups + 1023) / 1024, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(q_sample_quads_kernel<1>, dim3((groups + 255) / 256, a.B), dim3(256), 0, st, a);
+    SMD_LAUNCH_CHECK();
+    return 0;
+  }
   const dim3 grid((groups + 255) / 256, a.B);
   if ((a.S * a.C) % 4 == 0) hipLaunchKernelGGL(q_sample_kernel<true>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(q_sample_kernel<false>, grid, dim3(256), 0, st, a);

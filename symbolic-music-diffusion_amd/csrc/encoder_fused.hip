@@ -1303,13 +1303,29 @@ constexpr int AB_ST = AB_DQKV + 3 * 8192;      // per wave: max, 1/sum, row-dot 
 constexpr int AB_SMEM = AB_ST + 4 * 3 * 32 * 4;
 
 struct AttnBwdArgs {
-  const bf16_t* dh_mid;     // [R][128] gradient wrt the half-layer output (bf16)
+  const bf16_t* dh_mid;     // [R][128] gradient wrt the half-layer output (bf16); LNF: unused (produced in the kernel)
   const bf16_t* qkv;        // [R][384] saved (q unscaled)
   const bf16_t* Wo;         // out_proj kernel as W [in 128][out 128] bf16 (dgrad operand pack)
   const bf16_t* Wqkv;       // qkv kernel as W [in 128][out 384]
   bf16_t* dqkv;             // [R][384]
-  bf16_t* da1;              // [R][128]
+  bf16_t* da1;              // [R][128] (LNF: optional)
+  // ---- LNF (attn_block_bwd_kernel<DH, true>): the two LayerNorm backwards either side of the attention, in the same launch
+  const float* x2;          // [R][128] h_mid, the input of LayerNorm 2 (models/ncsn.py:164)
+  const float* parts;       // da2 as the four partial tiles the hidden-split MLP backward left, part_stride floats apart
+  size_t part_stride;
+  const float* gamma2;
+  float* dh;                // [R][128] fp32 residual-stream gradient: READ as the residual term of the LayerNorm-2 backward,
+                            // WRITTEN with the gradient that leaves the layer (output of the LayerNorm-1 backward); in place
+  bf16_t* dh_mid_out;       // [R][128] bf16 gradient between the two half-layers (operand of out_proj's weight gradient)
+  float* partial2;          // [R/32][2][128] dgamma | dbeta partial sums of LayerNorm 2, one slot per sample
+  const float* x1;          // [R][128] h, the input of LayerNorm 1 (models/ncsn.py:159)
+  const float* gamma1;
+  bf16_t* dh_out;           // [R][128] bf16 copy of the gradient that leaves the layer
+  float* partial1;          // [R/32][2][128] of LayerNorm 1
 };
+
+constexpr int AB_T1_LD = 264;                  // LNF: row stride of the da1 tile handed to the LayerNorm-1 backward (256 B + 8: conflict-free
+                                               // 8-byte column writes from the MFMA C layout, 4-byte row reads)
 
 __device__ __forceinline__ bf16x4_t tr_read(unsigned addr) {
   bf16x4_t v;
@@ -1324,7 +1340,16 @@ __device__ __forceinline__ bf16x4_t tr_read(unsigned addr) {
 // quarter.  The ds_read_b128 fragment reads (16 distinct r & 15 per lane group) are conflict-free under any bijection.
 __device__ __forceinline__ int ab_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-template <int DH>
+// LNF ("LayerNorm fused", engine option fused_attn_bwd = 2): the launch also runs the two 128-wide LayerNorm backwards that
+// bracket the attention in the backward pass -- until round 5 two launches of their own per layer (ln128_bwd_parts before,
+// layernorm_bwd_narrow128 after: 10 + 7 us of a 65 us layer, almost all of it launch / load latency):
+//   prologue  dh_mid = LN2-backward((p0 + p1) + (p2 + p3); h_mid, gamma2) + dh   -- wave w owns rows 8w .. 8w+7, a lane two columns,
+//             exactly the arithmetic of ln128_bwd_parts_kernel; the result goes to the LDS dh tile (instead of a DMA), to global
+//             memory as bf16 (out_proj's weight gradient reads it) and stays in registers as the residual term of the epilogue
+//   epilogue  dh    = LN1-backward(bf16(da1); h, gamma1) + dh_mid                -- da1 leaves the accumulators through an LDS tile
+//             (MFMA C layout -> row layout), same arithmetic again; fp32 in place + the bf16 copy the next layer reads
+// dgamma / dbeta partials: one [2][128] slot per sample and LayerNorm, folded over the four waves through LDS in a fixed order.
+template <int DH, bool LNF = false>
 __global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[AB_SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1344,15 +1369,77 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
   const __amdgpu_buffer_rsrc_t qkv_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(a.qkv + row0 * 384), 0, 32 * 768, 0x00020000);
 #pragma unroll
   for (int j = 0; j < 8; ++j) glds16(wo_rsrc, (uint32_t)rl * 256u + csw, (uint32_t)(j * 4096), lds_w + AB_W + j * 4096);
+  if constexpr (!LNF) {
 #pragma unroll
-  for (int j = 0; j < 2; ++j) glds16(dh_rsrc, (uint32_t)rl * 256u + csw, (uint32_t)(j * 4096), lds_w + AB_DH + j * 4096);
+    for (int j = 0; j < 2; ++j) glds16(dh_rsrc, (uint32_t)rl * 256u + csw, (uint32_t)(j * 4096), lds_w + AB_DH + j * 4096);
+  }
 #pragma unroll
   for (int pp = 0; pp < 3; ++pp)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
       glds16(qkv_rsrc, (uint32_t)rl * 768u + csw, (uint32_t)(pp * 256 + j * 16 * 768), lds_w + AB_QKV + pp * 8192 + j * 4096);
+  // ---- LNF prologue: LayerNorm-2 backward on this sample's 32 rows (row layout: wave w rows 8w .. 8w+7, lane = two columns)
+  float2 rv2[8], xv1[8], g1v;                       // dh_mid (fp32) and the LayerNorm-1 input rows / scale: live until the epilogue
+  if constexpr (LNF) {
+    const size_t r0 = row0 + (size_t)w * 8;
+    const float2 g2 = *reinterpret_cast<const float2*>(a.gamma2 + lane * 2);
+    float2 xv[8], dv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const size_t o = (r0 + i) * E_DIM + lane * 2;
+      xv[i] = *reinterpret_cast<const float2*>(a.x2 + o);
+      const float2 p0 = *reinterpret_cast<const float2*>(a.parts + o), p1 = *reinterpret_cast<const float2*>(a.parts + a.part_stride + o);
+      const float2 p2 = *reinterpret_cast<const float2*>(a.parts + 2 * a.part_stride + o), p3 = *reinterpret_cast<const float2*>(a.parts + 3 * a.part_stride + o);
+      dv[i].x = (p0.x + p1.x) + (p2.x + p3.x);
+      dv[i].y = (p0.y + p1.y) + (p2.y + p3.y);
+      rv2[i] = *reinterpret_cast<const float2*>(a.dh + o);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xv1[i] = *reinterpret_cast<const float2*>(a.x1 + (r0 + i) * E_DIM + lane * 2);
+    g1v = *reinterpret_cast<const float2*>(a.gamma1 + lane * 2);
+    float st[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st[2 * i] = xv[i].x + xv[i].y; st[2 * i + 1] = xv[i].x * xv[i].x + xv[i].y * xv[i].y; }
+    wave_allreduce_sum<16>(st);
+    float Px = 0.f, Py = 0.f, Qx = 0.f, Qy = 0.f;
+    float tt[16], rs[8];
+    float2 xh[8], dxh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float mean = st[2 * i] * (1.0f / E_DIM);
+      rs[i] = smd_ln_rstd(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      xh[i].x = (xv[i].x - mean) * rs[i];
+      xh[i].y = (xv[i].y - mean) * rs[i];
+      Qx += dv[i].x; Qy += dv[i].y;
+      Px += dv[i].x * xh[i].x; Py += dv[i].y * xh[i].y;
+      dxh[i].x = dv[i].x * g2.x; dxh[i].y = dv[i].y * g2.y;
+      tt[2 * i] = dxh[i].x + dxh[i].y;
+      tt[2 * i + 1] = dxh[i].x * xh[i].x + dxh[i].y * xh[i].y;
+    }
+    wave_allreduce_sum<16>(tt);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t1 = tt[2 * i] * (1.0f / E_DIM), t2 = tt[2 * i + 1] * (1.0f / E_DIM);
+      rv2[i].x = rs[i] * (dxh[i].x - t1 - xh[i].x * t2) + rv2[i].x;
+      rv2[i].y = rs[i] * (dxh[i].y - t1 - xh[i].y * t2) + rv2[i].y;
+      bf16x2_t t;
+      t[0] = f2bf(rv2[i].x); t[1] = f2bf(rv2[i].y);
+      *reinterpret_cast<bf16x2_t*>(a.dh_mid_out + (r0 + i) * E_DIM + lane * 2) = t;
+      const int r = w * 8 + i;                      // the dh tile as the DMA would have laid it out: 16-byte slot s at s ^ ab_swz(r & 15)
+      *reinterpret_cast<bf16x2_t*>(smem + AB_DH + r * 256 + (((lane >> 2) ^ ab_swz(r & 15)) << 4) + (lane & 3) * 4) = t;
+    }
+    float* red = reinterpret_cast<float*>(smem + AB_DQKV);          // [4 waves][2][128]: the dq | dk | dv tiles are not written before the next barrier but one
+    red[(w * 2 + 0) * E_DIM + lane * 2] = Px; red[(w * 2 + 0) * E_DIM + lane * 2 + 1] = Py;
+    red[(w * 2 + 1) * E_DIM + lane * 2] = Qx; red[(w * 2 + 1) * E_DIM + lane * 2 + 1] = Qy;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (LNF) {
+    const float* red = reinterpret_cast<const float*>(smem + AB_DQKV);
+    const int which = tid >> 7, c = tid & 127;
+    a.partial2[((size_t)blockIdx.x * 2 + which) * E_DIM + c] =
+        (red[(0 * 2 + which) * E_DIM + c] + red[(1 * 2 + which) * E_DIM + c]) + (red[(2 * 2 + which) * E_DIM + c] + red[(3 * 2 + which) * E_DIM + c]);
+  }
 
   // ---- dO^T (rows = in-features of out_proj = this wave's 32, cols = tokens) = Wo[i][:] . dh[token][:]
   {
@@ -1550,8 +1637,60 @@ __global__ __launch_bounds__(256) void attn_block_bwd_kernel(AttnBwdArgs a) {
       bf16x4_t v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = f2bf((c[0][4 * g + i] + c[1][4 * g + i]) + c[2][4 * g + i]);
-      *reinterpret_cast<bf16x4_t*>(a.da1 + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g) = v;
+      if (!LNF || a.da1) *reinterpret_cast<bf16x4_t*>(a.da1 + (row0 + l31) * E_DIM + w * 32 + 4 * kh + 8 * g) = v;
+      // LNF: the q | k | v tiles are dead (every wave has left the attention loop: the barrier above)
+      if constexpr (LNF) *reinterpret_cast<bf16x4_t*>(smem + AB_QKV + l31 * AB_T1_LD + (w * 32 + 4 * kh + 8 * g) * 2) = v;
     }
+  }
+  // ---- LNF epilogue: LayerNorm-1 backward in the row layout of the prologue, residual term = dh_mid still in registers
+  if constexpr (LNF) {
+    __syncthreads();
+    const size_t r0 = row0 + (size_t)w * 8;
+    float2 dv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16x2_t t = *reinterpret_cast<const bf16x2_t*>(smem + AB_QKV + (w * 8 + i) * AB_T1_LD + lane * 4);
+      dv[i].x = bf2f(t[0]); dv[i].y = bf2f(t[1]);
+    }
+    float st[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st[2 * i] = xv1[i].x + xv1[i].y; st[2 * i + 1] = xv1[i].x * xv1[i].x + xv1[i].y * xv1[i].y; }
+    wave_allreduce_sum<16>(st);
+    float Px = 0.f, Py = 0.f, Qx = 0.f, Qy = 0.f;
+    float tt[16], rs[8];
+    float2 xh[8], dxh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float mean = st[2 * i] * (1.0f / E_DIM);
+      rs[i] = smd_ln_rstd(st[2 * i + 1] * (1.0f / E_DIM) - mean * mean + LN_EPS);
+      xh[i].x = (xv1[i].x - mean) * rs[i];
+      xh[i].y = (xv1[i].y - mean) * rs[i];
+      Qx += dv[i].x; Qy += dv[i].y;
+      Px += dv[i].x * xh[i].x; Py += dv[i].y * xh[i].y;
+      dxh[i].x = dv[i].x * g1v.x; dxh[i].y = dv[i].y * g1v.y;
+      tt[2 * i] = dxh[i].x + dxh[i].y;
+      tt[2 * i + 1] = dxh[i].x * xh[i].x + dxh[i].y * xh[i].y;
+    }
+    wave_allreduce_sum<16>(tt);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float t1 = tt[2 * i] * (1.0f / E_DIM), t2 = tt[2 * i + 1] * (1.0f / E_DIM);
+      float2 o;
+      o.x = rs[i] * (dxh[i].x - t1 - xh[i].x * t2) + rv2[i].x;
+      o.y = rs[i] * (dxh[i].y - t1 - xh[i].y * t2) + rv2[i].y;
+      const size_t off = (r0 + i) * E_DIM + lane * 2;
+      *reinterpret_cast<float2*>(a.dh + off) = o;
+      bf16x2_t t;
+      t[0] = f2bf(o.x); t[1] = f2bf(o.y);
+      *reinterpret_cast<bf16x2_t*>(a.dh_out + off) = t;
+    }
+    float* red = reinterpret_cast<float*>(smem + AB_DO);            // dO is dead since the attention loop
+    red[(w * 2 + 0) * E_DIM + lane * 2] = Px; red[(w * 2 + 0) * E_DIM + lane * 2 + 1] = Py;
+    red[(w * 2 + 1) * E_DIM + lane * 2] = Qx; red[(w * 2 + 1) * E_DIM + lane * 2 + 1] = Qy;
+    __syncthreads();
+    const int which = tid >> 7, c = tid & 127;
+    a.partial1[((size_t)blockIdx.x * 2 + which) * E_DIM + c] =
+        (red[(0 * 2 + which) * E_DIM + c] + red[(1 * 2 + which) * E_DIM + c]) + (red[(2 * 2 + which) * E_DIM + c] + red[(3 * 2 + which) * E_DIM + c]);
   }
 }
 
@@ -1653,7 +1792,7 @@ int launch_attn_block_bwd(const bf16_t* dh_mid, const bf16_t* qkv, const bf16_t*
                           bf16_t* da1, int rows, int num_heads, hipStream_t st) {
   SMD_ARG_CHECK(dh_mid && qkv && Wo && Wqkv && dqkv && da1, "attn_block_bwd: null pointer");
   SMD_ARG_CHECK(rows > 0 && rows % S_TOK == 0, "attn_block_bwd: rows=%d must be a multiple of 32", rows);
-  AttnBwdArgs a;
+  AttnBwdArgs a = {};
   a.dh_mid = dh_mid; a.qkv = qkv; a.Wo = Wo; a.Wqkv = Wqkv; a.dqkv = dqkv; a.da1 = da1;
   const dim3 grid(rows / S_TOK), block(256);
   switch (num_heads) {
@@ -1661,6 +1800,25 @@ int launch_attn_block_bwd(const bf16_t* dh_mid, const bf16_t* qkv, const bf16_t*
     case 8: hipLaunchKernelGGL(attn_block_bwd_kernel<16>, grid, block, 0, st, a); break;
     case 16: hipLaunchKernelGGL(attn_block_bwd_kernel<8>, grid, block, 0, st, a); break;
     default: smd_set_error("attn_block_bwd: num_heads=%d unsupported (4, 8, 16)", num_heads); return -1;
+  }
+  SMD_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_attn_block_bwd_ln(const AttnBwdLnArgs& x, int rows, int num_heads, hipStream_t st) {
+  SMD_ARG_CHECK(x.qkv && x.Wo && x.Wqkv && x.dqkv && x.h_mid && x.da2_parts && x.gamma2 && x.dh && x.dh_mid_out && x.partial2 && x.h && x.gamma1 &&
+                x.dh_out && x.partial1, "attn_block_bwd_ln: null pointer");
+  SMD_ARG_CHECK(rows > 0 && rows % S_TOK == 0, "attn_block_bwd_ln: rows=%d must be a multiple of 32", rows);
+  AttnBwdArgs a = {};
+  a.dh_mid = nullptr; a.qkv = x.qkv; a.Wo = x.Wo; a.Wqkv = x.Wqkv; a.dqkv = x.dqkv; a.da1 = x.da1;
+  a.x2 = x.h_mid; a.parts = x.da2_parts; a.part_stride = x.part_stride; a.gamma2 = x.gamma2; a.dh = x.dh; a.dh_mid_out = x.dh_mid_out;
+  a.partial2 = x.partial2; a.x1 = x.h; a.gamma1 = x.gamma1; a.dh_out = x.dh_out; a.partial1 = x.partial1;
+  const dim3 grid(rows / S_TOK), block(256);
+  switch (num_heads) {
+    case 4: hipLaunchKernelGGL((attn_block_bwd_kernel<32, true>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((attn_block_bwd_kernel<16, true>), grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL((attn_block_bwd_kernel<8, true>), grid, block, 0, st, a); break;
+    default: smd_set_error("attn_block_bwd_ln: num_heads=%d unsupported (4, 8, 16)", num_heads); return -1;
   }
   SMD_LAUNCH_CHECK();
   return 0;

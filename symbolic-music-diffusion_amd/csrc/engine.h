@@ -182,7 +182,8 @@ class SmdEngine {
   int group_wgrad = 2;                                        // 128-wide weight gradients in grouped launches: 2 = one per encoder
                                                               // layer as soon as its backward is enqueued (+4.6 % train), 1 = all at
                                                               // the end of the backward (+3 %), 0 = one launch + reduce each
-  int fused_attn_bwd = 1;                                     // attn_block_bwd kernel (0: three separate launches)
+  int fused_attn_bwd = 2;                                     // attn_block_bwd kernel: 2 = with the LayerNorm backwards either side of it in the
+                                                              // launch (hidden-split dataflow), 1 = attention only, 0 = three separate launches
   int resgrad_bf16 = 1;   // ResBlock residual-gradient chain kept in bf16 (the GEMM operand copy) instead of fp32 + bf16
   int fused_encoder = 1;                                      // encoder_fused.hip half-layer kernels (0: separate launches)
   int side_wgrad = 0;

@@ -951,6 +951,11 @@ int SmdEngine::backward_stem(hipStream_t st) {
     bf16_t* dh_out = W.dhb[2 * l];
     snap(l, 4, W.dh);
     snap(l, 5, W.h_mid[l]);
+    // fused_attn_bwd = 2: the two LayerNorm backwards of the layer run inside the attention backward's launch (debug snapshots
+    // want the intermediate buffers of the separate kernels: they take the older path)
+    const bool attn_fused = fused_encoder && fused_attn_bwd && S == 32 && E == 128 && p.out.Np == E && p.qkv.Np == 3 * E;
+    const bool ln_fused = hs_train_ && attn_fused && fused_attn_bwd == 2 && !dbg_snap_;
+    float* partial2 = nullptr;
     if (hs_train_) {
       // fused backward with the hidden activations recomputed from a2: writes u and dz1 (wgrad operands) and four
       // partial tiles of da2; the ln2 backward sums them (launch-boundary reduce)
@@ -961,11 +966,11 @@ int SmdEngine::backward_stem(hipStream_t st) {
       RC(wgrad(p.fc1, W.a2[l], E, W.dz1[l], M, R, true, st));
       const size_t need = (size_t)(R / 32) * 2 * E;
       SMD_ARG_CHECK(ln_slot_off_ + need <= W.ln_partial_elems, "backward_stem: LayerNorm partial workspace exhausted");
-      float* partial = W.ln_partial + ln_slot_off_;
+      partial2 = W.ln_partial + ln_slot_off_;
       ln_slot_off_ += need;
-      RC(launch_ln128_bwd_parts(W.h_mid[l], W.mlp_part, (size_t)R * E, R, P(p.ln2.g_off), W.dh, W.dh, dh_mid, partial, st));
+      if (!ln_fused) RC(launch_ln128_bwd_parts(W.h_mid[l], W.mlp_part, (size_t)R * E, R, P(p.ln2.g_off), W.dh, W.dh, dh_mid, partial2, st));
       LnReduceEntry en;
-      en.partial = partial; en.ngroups = R / 32; en.D = E; en.dgamma = G(p.ln2.g_off); en.dbeta = G(p.ln2.b_off); en.block_start = 0;
+      en.partial = partial2; en.ngroups = R / 32; en.D = E; en.dgamma = G(p.ln2.g_off); en.dbeta = G(p.ln2.b_off); en.block_start = 0;
       ln_pending_.push_back(en);
       snap(l, 1, W.dh);
     } else {
@@ -978,7 +983,23 @@ int SmdEngine::backward_stem(hipStream_t st) {
       b.dgamma = G(p.ln2.g_off); b.dbeta = G(p.ln2.b_off);
       RC(ln_bwd(b, st));
     }
-    if (fused_encoder && fused_attn_bwd && S == 32 && E == 128 && p.out.Np == E && p.qkv.Np == 3 * E) {
+    if (ln_fused) {
+      // LayerNorm-2 backward + out_proj dgrad + attention backward + qkv dgrad + LayerNorm-1 backward in one launch
+      const size_t need = (size_t)(R / 32) * 2 * E;
+      SMD_ARG_CHECK(ln_slot_off_ + need <= W.ln_partial_elems, "backward_stem: LayerNorm partial workspace exhausted");
+      float* partial1 = W.ln_partial + ln_slot_off_;
+      ln_slot_off_ += need;
+      AttnBwdLnArgs x;
+      x.qkv = W.qkv[l]; x.Wo = wpack_ + p.out.W_off; x.Wqkv = wpack_ + p.qkv.W_off; x.dqkv = W.dqkv[l]; x.da1 = nullptr;
+      x.h_mid = W.h_mid[l]; x.da2_parts = W.mlp_part; x.part_stride = (size_t)R * E; x.gamma2 = P(p.ln2.g_off); x.dh = W.dh;
+      x.dh_mid_out = dh_mid; x.partial2 = partial2; x.h = W.h[l]; x.gamma1 = P(p.ln1.g_off); x.dh_out = dh_out; x.partial1 = partial1;
+      RC(launch_attn_block_bwd_ln(x, R, d_.num_heads, st));
+      RC(wgrad(p.out, W.o[l], E, dh_mid, E, R, true, st));           // (dh_mid is produced by the launch above)
+      RC(wgrad(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, true, st));
+      LnReduceEntry en;
+      en.partial = partial1; en.ngroups = R / 32; en.D = E; en.dgamma = G(p.ln1.g_off); en.dbeta = G(p.ln1.b_off); en.block_start = 0;
+      ln_pending_.push_back(en);
+    } else if (attn_fused) {
       // out_proj dgrad + attention backward + qkv dgrad in one launch; the two wgrads stay GEMMs
       RC(wgrad(p.out, W.o[l], E, dh_mid, E, R, true, st));
       RC(launch_attn_block_bwd(dh_mid, W.qkv[l], wpack_ + p.out.W_off, wpack_ + p.qkv.W_off, W.dqkv[l], W.dA_E, R,
@@ -990,7 +1011,7 @@ int SmdEngine::backward_stem(hipStream_t st) {
       RC(launch_attention_bwd(W.qkv[l], W.do_, W.dqkv[l], B, S, E, d_.num_heads, st));
       RC(dense_bwd(p.qkv, W.a1[l], E, W.dqkv[l], 3 * E, R, W.dA_E, E, nullptr, 0, SMD_AUX_NONE, st, true));
     }
-    {
+    if (!ln_fused) {
       LnBwdArgs b;
       b.f = ln_args(W.h[l], nullptr, R, p.ln1, params_);
       b.dout = W.dA_E; b.dres = W.dh; b.dx = W.dh; b.dx_bf16 = dh_out;

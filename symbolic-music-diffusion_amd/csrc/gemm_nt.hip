@@ -236,7 +236,7 @@ void launch_bm(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, int N
 // process-wide kernel-selection knobs (smd_set_tuning in the C-ABI)
 namespace {
 struct Knob { const char* key; int value; };
-Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_nt256_pk", 1}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 3}, {"gemm_nt_kg", 1}, {"mlp_hs_dbg", 0}, {"ln_excl", 0}, {"tn_exclusive_cu", 2}, {"tn_split_model", 1}, {"tn128_loader_waves", 1}, {"tn_mode", 0}, {"gemm_nt_form", 0}};
+Knob g_knobs[] = {{"gemm_nt256", 1}, {"gemm_nt256_variant", 0}, {"gemm_nt256_pk", 1}, {"gemm_tn256", 1}, {"ln_bwd_wide", 2}, {"ln_bwd_narrow", 1}, {"gemm_nt_deep", 1}, {"mlp_variant", 0}, {"tn128_target_wgs", 512}, {"gemm_tn_deep", 0}, {"ln_fwd_wide", 3}, {"gemm_nt_kg", 1}, {"mlp_hs_dbg", 0}, {"ln_excl", 0}, {"tn_exclusive_cu", 2}, {"tn_split_model", 1}, {"tn128_loader_waves", 1}, {"tn_mode", 0}, {"gemm_nt_form", 0}, {"gemm_nt_form_wk", 0}};
 }
 int smd_tuning_set(const char* key, int value) {
   for (Knob& k : g_knobs)
@@ -267,7 +267,10 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
   const long wg64 = (long)((M + 63) / 64) * tiles_n;
   const bool deep = K >= 8 * BK && smd_tuning_get("gemm_nt_deep");
   // measurement knob (tools/gemm_nt_forms_ab.py): force one tile form for the shapes that have a choice
-  const int form = M > 64 ? smd_tuning_get("gemm_nt_form") : 0;
+  // ("gemm_nt_form_wk": the same for the wide-K, few-column shapes only -- out_proj: N <= 512, K >= 2048 -- so that an in-step A/B
+  // of that one GEMM leaves every other launch on its default form)
+  const int form_wk = (M > 64 && N <= 512 && K >= 2048) ? smd_tuning_get("gemm_nt_form_wk") : 0;
+  const int form = form_wk ? form_wk : (M > 64 ? smd_tuning_get("gemm_nt_form") : 0);
   if (form == 1) launch_bm<64, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   else if (form == 2) launch_bm<128, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   else if (form == 3 && K % (2 * BK) == 0) launch_bm<128, 2, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);

@@ -42,9 +42,13 @@ __device__ __forceinline__ float4 philox_normal4(uint32_t idx4, uint32_t sample,
   const uint4 b = philox4x32_10(make_uint4(idx4, sample, stream, step), k0, k1);
   const float r0 = sqrtf(-2.0f * logf(u01(b.x)));
   const float r1 = sqrtf(-2.0f * logf(u01(b.z)));
-  float s0, c0, s1, c1;
-  sincosf(6.283185307179586f * u01(b.y), &s0, &c0);
-  sincosf(6.283185307179586f * u01(b.w), &s1, &c1);
+  // sin / cos of the angle 2 pi u on the transcendental unit: v_sin_f32 / v_cos_f32 take their argument in REVOLUTIONS, so the
+  // angle is u itself -- 4 instructions instead of two software sincosf with range reduction (~300 of the ~400 instructions of
+  // this function until round 6, which made q_sample and the reverse step VALU-bound at 2 TB/s: 1.05 M calls x 400 instructions
+  // = 9 us of issue slots on 1024 SIMDs).  Absolute error of a normal <= 2e-6 (tests/test_gpu_kernels.py prints it).
+  const float a0 = u01(b.y), a1 = u01(b.w);
+  const float s0 = __builtin_amdgcn_sinf(a0), c0 = __builtin_amdgcn_cosf(a0);
+  const float s1 = __builtin_amdgcn_sinf(a1), c1 = __builtin_amdgcn_cosf(a1);
   return make_float4(r0 * c0, r0 * s0, r1 * c1, r1 * s1);
 }
 __device__ __forceinline__ float pick4(const float4& v, int i) {

@@ -201,6 +201,31 @@ int launch_attn_block_fwd(const float* h_in, float* h_out, int rows, const float
 int launch_attn_block_bwd(const bf16_t* dh_mid, const bf16_t* qkv, const bf16_t* Wo, const bf16_t* Wqkv, bf16_t* dqkv,
                           bf16_t* da1, int rows, int num_heads, hipStream_t st);
 
+// The same launch WITH the two LayerNorm backwards that bracket the attention in the backward pass (hidden-split MLP dataflow):
+//   dh_mid = LN2-backward((p0 + p1) + (p2 + p3) of da2_parts; h_mid, gamma2) + dh     -> dh_mid_out (bf16), partial2
+//   ... attention half-layer backward from dh_mid ...                                  -> dqkv (, da1)
+//   dh     = LN1-backward(bf16(da1); h, gamma1) + dh_mid                               -> dh (fp32, IN PLACE), dh_out (bf16), partial1
+// partial1 / partial2: [rows/32][2][128] dgamma | dbeta sums per sample (reduced by launch_ln_bwd_reduce_batched).
+struct AttnBwdLnArgs {
+  const bf16_t* qkv = nullptr;        // [R][384] saved q | k | v
+  const bf16_t* Wo = nullptr;         // dgrad operand packs W [in][out]
+  const bf16_t* Wqkv = nullptr;
+  bf16_t* dqkv = nullptr;             // [R][384]
+  bf16_t* da1 = nullptr;              // [R][128], optional
+  const float* h_mid = nullptr;       // [R][128] input of LayerNorm 2
+  const float* da2_parts = nullptr;   // four partial tiles, part_stride floats apart
+  size_t part_stride = 0;
+  const float* gamma2 = nullptr;
+  float* dh = nullptr;                // [R][128] fp32 residual-stream gradient (read, then overwritten)
+  bf16_t* dh_mid_out = nullptr;       // [R][128]
+  float* partial2 = nullptr;
+  const float* h = nullptr;           // [R][128] input of LayerNorm 1
+  const float* gamma1 = nullptr;
+  bf16_t* dh_out = nullptr;           // [R][128]
+  float* partial1 = nullptr;
+};
+int launch_attn_block_bwd_ln(const AttnBwdLnArgs& a, int rows, int num_heads, hipStream_t st);
+
 // ------------------------------------------------------------------ diffusion elementwise (diffusion.hip)
 // sinusoidal noise embedding, reference models/ncsn.py:28-41: s[n] -> bf16 [n][channels]
 int launch_noise_embed(const float* s, int n, int channels, bf16_t* out, int ld_out, hipStream_t st);

@@ -54,7 +54,7 @@ class LangevinIO(C.Structure):
                 ("steps_per_level", c_i32), ("n_levels", c_i32)]
 
 
-ABI_VERSION = 5          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
+ABI_VERSION = 6          # SMD_ABI_VERSION of include/smd_hip.h this table was written against
 
 # name -> (restype, argtypes).  Pointers are passed as integers (tensor.data_ptr()) via c_void_p.
 _SIGS = {
@@ -121,6 +121,8 @@ _SIGS = {
     "smd_attn_block_fwd": (C.c_int, [c_void, c_void, C.c_int, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, c_void,
                                      c_void, c_void, c_void]),
     "smd_attn_block_bwd": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
+    "smd_attn_block_bwd_ln": (C.c_int, [c_void, c_void, c_void, c_void, c_void, c_void, c_void, C.c_int64, c_void, c_void, c_void, c_void,
+                                        c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void]),
     "smd_gemm_bf16_tn": (C.c_int, [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, C.c_int,
                                    c_void, c_void, c_void, c_i64, c_void, c_i64, C.c_int, c_void]),
     "smd_gemm_tn_slab_elems": (c_i64, []),

@@ -1020,3 +1020,40 @@ def test_sample_step_parts_compose_to_the_whole_step_bitwise(arch, C, K, dtype):
         assert got[2] == 996 and torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), f"split {split}"
     with pytest.raises(ValueError):
         eng.sample_step(io, 3)
+
+
+@pytest.mark.parametrize("C,L,H,K,B", [(512, 6, 8, 2, 256), (146, 2, 16, 3, 8), (512, 8, 16, 3, 128)])
+def test_layernorm_backwards_inside_the_attention_backward_launch(C, L, H, K, B):
+    """Engine option fused_attn_bwd = 2 (default since round 6): per encoder layer ONE launch runs LayerNorm-2 backward, the
+    attention backward and LayerNorm-1 backward (csrc/encoder_fused.hip attn_block_bwd_kernel<d, true>) instead of three.  Against
+    the three-launch path (= 1; what test_encoder_backward_chain_from_snapshots checks kernel by kernel against fp64): the loss is
+    bitwise the same and the two gradients differ by fp32 summation order in the LayerNorm-1 backward (the stand-alone kernel adds its
+    rows in another order) AMPLIFIED by bf16 storage: a 1e-7 difference in dh flips the rounding of about one element in 10^4 of its
+    bf16 copy, a whole bf16 step, and every layer below inherits it -- measured 3.4e-5 on the whole gradient, 1.3e-3 on in_proj's (the end
+    of the chain) at L = 6, the same mechanism and size as the inference-vs-training-path difference documented at
+    test_forward_against_the_bf16_emulating_oracle.  Bounds: 1e-4 / 5e-3.  The fused path is bitwise repeatable."""
+    ocfg, p, model = make("TransformerDDPM", C, L, H, K)
+    x0, g = data(B, (32, C))
+    labels = torch.randint(1, 1001, (B,), generator=g)
+    eps = torch.randn(B, 32, C, generator=g)
+    eng = model.train_engine(ema=False)
+    eng.set_schedule(BETAS, with_sampler=False)
+    eng.bind(B, training=True)
+    out = {}
+    for mode in (2, 1, 2):
+        eng.set_option("fused_attn_bwd", mode)
+        eng.grads.fill_(float("nan"))
+        eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=0)
+        torch.cuda.synchronize()
+        out.setdefault(mode, []).append((eng.grads.clone(), eng.loss_per_sample().clone()))
+    (g2, l2), (g2b, l2b) = out[2]
+    (g1, l1), = out[1]
+    assert bool(torch.isfinite(g2).all())
+    assert torch.equal(g2, g2b) and torch.equal(l2, l2b)                       # repeatable
+    assert torch.equal(l2, l1)
+    v2, v1 = eng.named_views(g2), eng.named_views(g1)
+    worst = max((rel(v2[k], v1[k]), k) for k in v1 if float(v1[k].norm()) > 0)
+    print(f"fused LayerNorm backwards C={C} L={L} B={B}: whole gradient rel {rel(g2, g1):.2e}, worst tensor {worst[1]} {worst[0]:.2e}")
+    assert rel(g2, g1) < 1e-4 and worst[0] < 5e-3
+    assert not torch.equal(g2, g1) or L == 0                                     # the other path really ran
+    eng.set_option("fused_attn_bwd", 2)

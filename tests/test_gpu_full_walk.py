@@ -113,7 +113,7 @@ def test_full_T_walk_graph_replay_equals_eager_bitwise():
 
 
 # ------------------------------------------------------------------ (b) trained weights
-def _train(model, steps, B=256, C=512, lr=1e-3):
+def _train(model, steps, B=256, C=512, lr=1e-3, at=None):
     """`steps` engine train steps (configs/ddpm-base.cfg: Adam, lr 1e-3, grad_clip 1) on structured synthetic latents -- a
     low-rank pattern + noise drawn on the device, so the net has something to fit and its FiLM / LayerNorm statistics move --
     with the engine's own Philox label / eps draws."""
@@ -130,6 +130,8 @@ def _train(model, steps, B=256, C=512, lr=1e-3):
     opt = create_optimizer(model, lr, ema=False)
     losses = []
     for it in range(steps):
+        if at and it in at:
+            at[it](it, opt, x0.cpu())       # a look at the state after `it` steps (x0: the batch of the step before)
         x0 = batch()
         _, m = train_step(N.diffusion_loss, x0, opt, BETAS, N.PRNGKey(it), lr, grad_clip=1.0)
         if it % 100 == 0 or it == steps - 1:
@@ -144,7 +146,39 @@ def test_parity_on_trained_weights(dtype):
     import smd_amd.ncsn as N
     B, C = 256, 512
     ocfg, p0, model = make(C, 6, 8, 2, dtype=dtype)
-    opt, losses, x_last = _train(model, 1500)
+
+    def plateau(it, opt, x0):
+        """The predict-zero plateau (VERDICT r5 weak #1c).  On the way down from loss 2.0 the net passes through "output (almost)
+        nothing": loss ~1.0, |eps_hat| a fraction of |eps| (where a run lingers there depends on the box: round 5's first run of this
+        test sat at 1.003 for 300 steps, later runs are through it by step ~50).  The RELATIVE eps_hat error in that state is the bf16
+        noise of the trunk -- which does not shrink with the output -- divided by a vanishing output: 4.5e-2 in that run, above
+        SURVEY 8c's 1e-2; the quantity the loss and the sampler consume is eps_hat itself next to eps / x: asserted here as an
+        ABSOLUTE bound, error / |eps| <= 1e-2, at several points of the descent and at step 300, with the relative figure and
+        |eps_hat| / |eps| printed beside it."""
+        eng = opt.engine
+        q = {k: v.detach().float().cpu().clone() for k, v in model.engine.named_views().items()}
+        gp = torch.Generator().manual_seed(300)
+        labels, eps = torch.randint(1, 1001, (B,), generator=gp), torch.randn(B, 32, C, generator=gp)
+        seen = {}
+        base = O.make_model(q, ocfg)
+
+        def capturing(x, cond):
+            seen["pred"] = base(x, cond)
+            return seen["pred"]
+        with torch.no_grad():
+            l_ref = float(O.diffusion_loss(x0, capturing, BETAS, labels.numpy(), eps, "mean"))
+        eng.loss_backward(x0.cuda(), labels.int().cuda(), eps.cuda(), stage=3)
+        torch.cuda.synchronize()
+        pred = eng.last_pred().double().cpu()
+        err = float((pred - seen["pred"].double()).norm())
+        n_pred, n_eps = float(seen["pred"].double().norm()), float(eps.double().norm())
+        l_eng = float(eng.loss_per_sample().mean())
+        print(f"[plateau {dtype}] after {it} steps: loss {l_eng:.5f} (oracle {l_ref:.5f}); |eps_hat| / |eps| = {n_pred / n_eps:.3f}; eps_hat error: "
+              f"relative {err / n_pred:.3e}, ABSOLUTE (error / |eps|) {err / n_eps:.3e}")
+        assert err / n_eps < 1e-2
+        assert abs(l_eng - l_ref) / l_ref < 5e-3
+
+    opt, losses, x_last = _train(model, 1500, at={10: plateau, 20: plateau, 40: plateau, 300: plateau})
     print(f"[trained {dtype}] loss every 100 of the 1500 steps: " + " ".join(f"{v:.3f}" for v in losses))
     assert losses[-1] < 0.9, "training did not get below the predict-zero plateau (loss 1.0)"
     eng = opt.engine
@@ -193,14 +227,19 @@ def test_parity_on_trained_weights(dtype):
               f"|g| {den ** 0.5:.4f}; gradient whole-vector rel {e_grad:.3e}, cosine {cos:.6f}")
         assert e_pred < tol_fwd
         assert abs(m_eng - m_ref) / m_ref < (5e-3 if dtype == "bf16" else 2.5e-2)
-        assert cos > (0.998 if dtype == "bf16" else 0.98) and e_grad < (8e-2 if dtype == "bf16" else 2.5e-1)
+        # bounds = measured x 1.5 (profiles/r5f_trained_tests.txt: bf16 3.9e-2 ... 4.1e-2, fp8 6.3e-2 ... 6.6e-2); what they measure is
+        # attributed below (bf16: bf16_emulation.py; fp8: e4m3_emulation.py) and shown harmless by tests/test_gpu_trajectory.py
+        assert cos > (0.998 if dtype == "bf16" else 0.996) and e_grad < (6.2e-2 if dtype == "bf16" else 1.0e-1)
     # ---- the sharp gradient check on trained weights: against the oracle WITH THE ENGINE'S ROUNDING POINTS (oracle/bf16_emulation.py:
     # bf16 operand pack, bf16 activations where the engine stores bf16, gradient hooks), B = 8, fp64.  The 4e-2 above is the gradient
     # of a slightly different function -- the loss at the bf16-ROUNDED weights -- divided by a mean gradient that training has
     # driven towards zero; the emulating oracle evaluates that same function, so what is left is the kernels' own error.
-    if dtype == "bf16":
+    # fp8: the same with oracle/e4m3_emulation.py (e4m3 operands + E8M0 row scales of the DenseResBlock forward and dgrad GEMMs on top).
+    if True:
         import bf16_emulation as E
+        import e4m3_emulation as F8
         import smd_amd.lib as _lib
+        EMU = E if dtype == "bf16" else F8
         B8 = 8
         x8, lab8, eps8 = x_last[:B8], torch.randint(1, 1001, (B8,), generator=g), torch.randn(B8, 32, C, generator=g)
         p64 = {k: v.double() for k, v in p.items()}
@@ -225,8 +264,8 @@ def test_parity_on_trained_weights(dtype):
             return (num / den) ** 0.5, den ** 0.5
 
         (e_exact, gnorm), (e_emu, _) = dist(oracle8(lambda q: O.make_model(q, ocfg))), dist(oracle8(
-            lambda q: E.make_model(q, ocfg, backward=True, noise_embedding=emb.double().cpu())))
-        print(f"[trained bf16] B = 8 gradient (|g| {gnorm:.4f}): vs the exact fp64 oracle {e_exact:.3e}; vs the oracle with the engine's "
+            lambda q: EMU.make_model(q, ocfg, backward=True, noise_embedding=emb.double().cpu())))
+        print(f"[trained {dtype}] B = 8 gradient (|g| {gnorm:.4f}): vs the exact fp64 oracle {e_exact:.3e}; vs the oracle with the engine's "
               f"rounding points {e_emu:.3e}")
         assert e_emu < 1e-2 and e_emu < 0.5 * e_exact
         eng.bind(B, training=True)

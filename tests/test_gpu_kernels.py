@@ -501,6 +501,85 @@ def test_attn_block_bwd_fused(L, dev, rows, H):
     assert e_a < 4e-3
 
 
+@pytest.mark.parametrize("rows,H", [(32, 8), (96, 16), (64, 4), (8192, 8)])
+def test_attn_block_bwd_with_both_layernorm_backwards(L, dev, rows, H):
+    """smd_attn_block_bwd_ln (round 6): LayerNorm-2 backward on the four da2 partial tiles + residual, the attention half-layer
+    backward, LayerNorm-1 backward + residual in ONE launch (models/ncsn.py:159-164 backwards).  Checked (i) against fp64 of its own
+    inputs, stage by stage, and (ii) against the three launches it replaces (smd_ln128_bwd_parts -> smd_attn_block_bwd ->
+    smd_layernorm_bwd_ex): dh_mid and dqkv bitwise (the same arithmetic on the same layout), the final dh to fp32 rounding (the
+    stand-alone LayerNorm-1 kernel sums its rows in another order)."""
+    g = torch.Generator().manual_seed(11 * rows + H)
+    E, d, B = 128, 128 // H, rows // 32
+    h_mid = torch.randn(rows, E, generator=g) * 1.3 + 0.2
+    h = torch.randn(rows, E, generator=g) * 0.9 - 0.1
+    parts = torch.randn(4, rows, E, generator=g) * 0.02
+    dh = torch.randn(rows, E, generator=g) * 0.05
+    g2, g1 = 1 + 0.2 * torch.randn(E, generator=g), 1 + 0.2 * torch.randn(E, generator=g)
+    qkv = bf(torch.randn(rows, 3 * E, generator=g) * 0.8)
+    Wo = bf(torch.randn(E, E, generator=g) * 0.09)
+    Wqkv = bf(torch.randn(E, 3 * E, generator=g) * 0.09)
+
+    def ln_bwd64(x, gamma, dout):
+        xr = x.double().requires_grad_(True)
+        gr, br = gamma.double().requires_grad_(True), torch.zeros(E, dtype=torch.float64, requires_grad=True)
+        O.layer_norm(xr, {"n.scale": gr, "n.bias": br}, "n").backward(dout.double())
+        return xr.grad, gr.grad, br.grad
+
+    Dv = lambda t: t.to(dev)
+    hmD, hD, pD, g2D, g1D, qkvD, WoD, WqD = Dv(h_mid), Dv(h), Dv(parts.contiguous()), Dv(g2), Dv(g1), Dv(qkv), Dv(Wo), Dv(Wqkv)
+    dhD = Dv(dh).clone()
+    dq = torch.zeros(rows, 3 * E, dtype=torch.bfloat16, device=dev)
+    da1 = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    dh_mid_o = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    dh_o = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    p2 = torch.zeros(rows // 32, 2, E, device=dev)
+    p1 = torch.zeros(rows // 32, 2, E, device=dev)
+    ck(L, L.smd_attn_block_bwd_ln(P(qkvD), P(WoD), P(WqD), P(dq), P(da1), P(hmD), P(pD), rows * E, P(g2D), P(dhD), P(dh_mid_o), P(p2),
+                                  P(hD), P(g1D), P(dh_o), P(p1), rows, H, st()))
+    torch.cuda.synchronize()
+    # ---- (i) fp64, stage by stage
+    da2 = parts.double().sum(0)
+    dx2, dg2, db2 = ln_bwd64(h_mid, g2, da2)
+    dh_mid_ref = dx2 + dh.double()
+    e_mid = rel(dh_mid_o.float(), dh_mid_ref)
+    do = bf((dh_mid_o.double().cpu() @ Wo.double().t()).float())
+    leaf = qkv.double().clone().requires_grad_(True)
+    q, k, v = [t.view(B, 32, H, d).transpose(1, 2) for t in leaf.split(E, dim=-1)]
+    pr = torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), dim=-1)
+    ((pr @ v).transpose(1, 2).reshape(rows, E) * do.double()).sum().backward()
+    e_qkv = rel(dq.float(), leaf.grad)
+    da1_ref = bf((dq.double().cpu() @ Wqkv.double().t()).float())
+    e_a1 = rel(da1.float(), da1_ref.float())
+    dx1, dg1, db1 = ln_bwd64(h, g1, da1.double().cpu())
+    dh_ref = dx1 + dh_mid_ref
+    e_dh = rel(dhD.double().cpu() - dh_mid_ref, dx1)             # the LayerNorm-1 term alone, the residual taken out
+    e_tot = rel(dhD, dh_ref)
+    e_g = max(rel(p2[:, 0].sum(0), dg2), rel(p2[:, 1].sum(0), db2), rel(p1[:, 0].sum(0), dg1), rel(p1[:, 1].sum(0), db1))
+    print(f"attn_block_bwd_ln rows={rows} H={H}: dh_mid {e_mid:.2e} dqkv {e_qkv:.2e} da1 {e_a1:.2e} LN1 term {e_dh:.2e} dh {e_tot:.2e} "
+          f"dgamma/dbeta {e_g:.2e}; dh_out(bf16) {rel(dh_o.float(), dh_ref):.2e}")
+    assert e_mid < 4e-3 and e_qkv < 1e-2 and e_a1 < 4e-3
+    assert e_dh < 1e-4 and e_tot < 1e-5 and e_g < 1e-4
+    assert rel(dh_o.float(), dh_ref) < 4e-3
+    # ---- (ii) the three launches it replaces
+    dh3 = Dv(dh).clone()
+    mid3 = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    q3 = torch.zeros(rows, 3 * E, dtype=torch.bfloat16, device=dev)
+    a3 = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    o3 = torch.zeros(rows, E, dtype=torch.bfloat16, device=dev)
+    p23 = torch.zeros(rows // 32, 2, E, device=dev)
+    part3 = torch.zeros(rows // 32 * 2 * E, device=dev)
+    dg3, db3 = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+    b0 = torch.zeros(E, device=dev)
+    ck(L, L.smd_ln128_bwd_parts(P(hmD), P(pD), rows * E, rows, P(g2D), P(dh3), P(dh3), P(mid3), P(p23), st()))
+    ck(L, L.smd_attn_block_bwd(P(mid3), P(qkvD), P(WoD), P(WqD), P(q3), P(a3), rows, H, st()))
+    ck(L, L.smd_layernorm_bwd_ex(P(hD), None, rows, E, P(g1D), P(b0), P(a3), P(dh3), P(dh3), P(o3), P(dg3), P(db3), P(part3), part3.numel(), st()))
+    torch.cuda.synchronize()
+    assert torch.equal(mid3, dh_mid_o) and torch.equal(q3, dq) and torch.equal(a3, da1)
+    assert rel(p2, p23) < 1e-6                   # (the two translation units contract the P / Q accumulations differently: last-bit differences)
+    assert rel(dhD, dh3) < 2e-6 and rel(p1[:, 0].sum(0), dg3) < 1e-5 and rel(p1[:, 1].sum(0), db3) < 1e-5
+    assert float((dh_o.float() - o3.float()).abs().max()) <= float(o3.float().abs().max()) * 2 ** -7       # at most one bf16 step apart
+
+
 @pytest.mark.parametrize("D,film,swish", [(128, False, False), (2048, False, False), (2048, True, True),
                                           (512, True, True), (1024, True, False)])
 def test_layernorm_fwd_bwd(L, dev, D, film, swish):

@@ -18,9 +18,14 @@ def short(n):
     n = n.strip()
     if n.startswith("void "):
         n = n[5:]
-    m = re.search(r"\d+([A-Za-z0-9_]+_kernel)", n) if n.startswith("_Z") else None
-    if m:
-        return m.group(1)
+    n = n.replace("(anonymous namespace)::", "")
+    if n.startswith("_Z"):             # an Itanium-mangled name the trace did not demangle: the <length><identifier> that ends in _kernel
+        for m in re.finditer(r"(\d+)", n):
+            ln, st = int(m.group(1)), m.end()
+            while ln >= 100 and st > m.start():          # "N_122ln128..." reads as 122: drop leading digits that belong to the prefix
+                ln = int(str(ln)[1:])
+            if n[st:st + ln].endswith("_kernel"):
+                return n[st:st + ln]
     depth, out = 0, []
     for ch in n:                       # up to the argument list: the first '(' outside template brackets
         if ch == "<":
