@@ -155,8 +155,9 @@ __global__ __launch_bounds__(256) void q_sample_quads_kernel(QSampleArgs a) {
     srow += ((srow + 1) * a.C <= e);
     const int c = e - srow * a.C;
     bf16x4_t t;
-    t[0] = f2bf(sa * x0[k].x + sb * eps.x); t[1] = f2bf(sa * x0[k].y + sb * eps.y);
-    t[2] = f2bf(sa * x0[k].z + sb * eps.z); t[3] = f2bf(sa * x0[k].w + sb * eps.w);
+    // (explicit fma: both instantiations -- and a shard of the batch that takes the other one -- round identically)
+    t[0] = f2bf(__builtin_fmaf(sb, eps.x, sa * x0[k].x)); t[1] = f2bf(__builtin_fmaf(sb, eps.y, sa * x0[k].y));
+    t[2] = f2bf(__builtin_fmaf(sb, eps.z, sa * x0[k].z)); t[3] = f2bf(__builtin_fmaf(sb, eps.w, sa * x0[k].w));
     *reinterpret_cast<bf16x4_t*>(a.xt_bf16 + ((size_t)b * a.S + srow) * a.Cp + c) = t;
     *reinterpret_cast<float4*>(a.eps_out + sbase + (size_t)e) = eps;
   }

@@ -277,7 +277,12 @@ int launch_gemm_nt(const bf16_t* A, int lda, const bf16_t* Bt, int ldb, int M, i
   else if (form == 4 && K % (2 * BK) == 0) launch_bm<64, 2, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   else if (form == 5) launch_bm<128, 3>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
   else if (form == 6 && K % (2 * BK) == 0) launch_bm<64, 3, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
-  else if (M <= 32 || !(wg128 >= 512 || wg64 >= 256 || M <= 64)) {
+  else if (N <= 512 && K >= 2048 && K % (2 * BK) == 0 && M >= 2048 && smd_tuning_get("gemm_nt_kg") && smd_tuning_get("gemm_nt_form_wk") == 0) {
+    // out_proj (models/ncsn.py:177-178: rows x 2048 -> 512): 128-row tiles with two K-groups of four waves -- half the operand
+    // traffic per flop of the 64-row form and two waves per SIMD on one tile.  In-step A/B (profiles/r6d_schedule_and_out_proj_form_ab.txt):
+    // sample step +2 ... +3 % (1849 / 1855 -> 1914 / 1885 steps/s), train step unchanged
+    launch_bm<128, 2, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
+  } else if (M <= 32 || !(wg128 >= 512 || wg64 >= 256 || M <= 64)) {
     // K >= 1024: two K-groups of four waves per workgroup (A/B: 8-18 % over one group with a 4-deep ring; deeper rings
     // -- 7 stages, or 2 groups x 4 stages -- gain nothing: the step time follows the LDS-DMA landing cadence)
     if (deep && K >= 16 * BK && K % (2 * BK) == 0 && smd_tuning_get("gemm_nt_kg")) launch_bm<32, 3, 2>(A, lda, Bt, ldb, M, N, K, vec, ep, st);
