@@ -364,21 +364,23 @@ class GradComm:
 
 
 def device_identity(index: Optional[int] = None) -> str:
-    """A string that names the PHYSICAL device behind ``cuda:index`` of this process: its UUID when the runtime reports one,
-    else PCI domain:bus:device, else the ordinal -- what the bench line lists per rank so that N ranks can be seen to sit on
-    N distinct GPUs (a CPU-only process reports ``cpu:<hostname>:<pid>``)."""
+    """A string that names the PHYSICAL device behind ``cuda:index`` of this process: its UUID and its PCI domain:bus:device as far as
+    the runtime reports them, else the ordinal -- what the bench line lists per rank so that N ranks can be seen to sit on N distinct
+    GPUs (a CPU-only process reports ``cpu:<hostname>:<pid>``)."""
     if not torch.cuda.is_available():
         import socket
         return f"cpu:{socket.gethostname()}:{os.getpid()}"
     i = torch.cuda.current_device() if index is None else int(index)
     pr = torch.cuda.get_device_properties(i)
+    parts = []
     uuid = getattr(pr, "uuid", None)
     if uuid is not None and str(uuid).strip("0-") != "":
-        return f"uuid:{uuid}"
+        parts.append(f"uuid:{uuid}")
     bus = getattr(pr, "pci_bus_id", None)
     if bus is not None:
-        return f"pci:{getattr(pr, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(pr, 'pci_device_id', 0):02x}"
-    return f"ordinal:{i}"
+        parts.append(f"pci:{getattr(pr, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(pr, 'pci_device_id', 0):02x}")
+    # (both when both exist: two ranks count as sharing a device only if EVERY identifier the runtime gives agrees)
+    return "|".join(parts) if parts else f"ordinal:{i}"
 
 
 def gather_device_identities(dist=None, group=None, mine: Optional[str] = None) -> List[str]:
