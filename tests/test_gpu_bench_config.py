@@ -364,6 +364,10 @@ def test_bench_script_with_two_ranks_on_one_gpu():
     assert dp["backend"] == "gloo" and dp["world_size"] == 2 and dp["algorithm"] == "all_reduce" and dp["layer_buckets"] is False
     assert dp["collectives_per_step"] == 2.0                                 # output-stage slice + stem slice, nothing else
     assert dp["exposed_comm_us"] is not None and dp["exposed_comm_us"] >= 0
+    # ... and on which devices: one identity per rank (GPU UUID and / or PCI address), here twice the same one -- which the script
+    # accepts only because of the test hook (without it, ranks that share a device print no line: tests/test_host.py)
+    assert len(dp["devices"]) == 2 and dp["devices"][0] == dp["devices"][1] and dp["distinct_devices"] == 1
+    assert d["config"]["devices"] == dp["devices"] and any(t in dp["devices"][0] for t in ("uuid:", "pci:", "ordinal:"))
 
 
 def test_bench_dp_dry_run_on_one_gpu():
